@@ -1,0 +1,340 @@
+"""ctypes bindings for the two CPU oracles (TEST INFRASTRUCTURE).
+
+``load("port")`` -> liborc.so (plain-C restatement), ``load("reference")`` -> the real
+reference build.  Both are wrapped by :class:`OracleVfo`, whose method names follow the
+reference's ``vfo`` class (vfo.h:16-49) so parity tests read like reference-side code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_SO = os.path.join(_HERE, "liborc.so")
+REF_SO = os.path.join(_HERE, "_ref", "libsdrref.so")
+
+_vp, _i, _d, _f, _l = C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_long
+
+
+def build_port(force: bool = False) -> str:
+    """Compile oracle/vfo_oracle.c with gcc (a few hundred ms)."""
+    src = os.path.join(_HERE, "vfo_oracle.c")
+    if force or not os.path.exists(PORT_SO) or os.path.getmtime(PORT_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liborc.so"], stdout=subprocess.DEVNULL)
+    return PORT_SO
+
+
+def build_reference(ref_root: str = "/root/reference") -> str | None:
+    """Compile the real reference into oracle/_ref/ -- only where its sources exist."""
+    if not os.path.isdir(ref_root):
+        return REF_SO if os.path.exists(REF_SO) else None
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "ref"), f"REF={ref_root}"],
+                          stdout=subprocess.DEVNULL)
+    return REF_SO
+
+
+class _Lib:
+    """Uniform view of either library: prefix ``orc_`` or ``ref_``."""
+
+    def __init__(self, kind: str):
+        self.kind = kind
+        if kind == "port":
+            build_port()
+            self.lib = C.CDLL(PORT_SO)
+            self.p = "orc_"
+        elif kind == "reference":
+            if not os.path.exists(REF_SO):
+                raise FileNotFoundError(REF_SO)
+            self.lib = C.CDLL(REF_SO)
+            self.p = "ref_"
+        else:
+            raise ValueError(kind)
+        self._sig()
+
+    def fn(self, name):
+        return getattr(self.lib, self.p + name)
+
+    def _sig(self):
+        s = self.fn
+        s("vfo_new").restype = _vp
+        s("vfo_new").argtypes = []
+        s("vfo_free").argtypes = [_vp]
+        s("vfo_set_fs").argtypes = [_vp, _i]
+        s("vfo_set_decimation_count").argtypes = [_vp, _i]
+        s("vfo_set_mixer_freq").argtypes = [_vp, _d]
+        s("vfo_set_demod_usb").argtypes = [_vp, _i]
+        s("vfo_set_filter_bandwidth").argtypes = [_vp, _d]
+        s("vfo_set_gain").argtypes = [_vp, _f]
+        s("vfo_set_compression_style").argtypes = [_vp, _i]
+        s("vfo_set_scale_comp").argtypes = [_vp, _i]
+        s("vfo_add_child").argtypes = [_vp, _vp]
+        s("vfo_process").argtypes = [_vp, _vp, _i]
+        s("vfo_decimate_count").argtypes = [_vp]
+        s("vfo_output_rate").argtypes = [_vp]
+        s("vfo_output_rate").restype = C.c_uint
+        s("vfo_get_stream").argtypes = [_vp, _i, _vp, _i]
+        s("vfo_get_usb").argtypes = [_vp, _vp, _i]
+        s("vfo_get_iq").argtypes = [_vp, _vp, _i]
+        s("vfo_get_fir_usb_taps").argtypes = [_vp, _vp, _i]
+        s("vfo_get_fir_dec_taps").argtypes = [_vp, _vp, _i]
+        s("vfo_get_hilbert_taps").argtypes = [_vp, _vp, _i]
+        s("osc_sequence").argtypes = [_d, _d, _l, _vp]
+        s("osc_sequence").restype = None
+        s("low_pass").argtypes = [_d, _d, _d, _d, _vp, _i]
+        s("hilbert_taps").argtypes = [_i, _i, _vp]
+        if self.kind == "port":
+            s("vfo_init").argtypes = [_vp, _i, _i]
+            s("vfo_set_topic").argtypes = [_vp, C.c_char_p]
+            s("vfo_get_usb_prequant").argtypes = [_vp, _vp, _i]
+            s("process_roots").argtypes = [_vp, _i, _vp, _i, _i, _i]
+            s("osc_table").argtypes = [_d, _d, _vp]
+            s("osc_table").restype = _l
+            s("dc_correct").argtypes = [_vp, _i, _vp]
+            s("u8_to_float").argtypes = [_vp, _i, _vp]
+            s("double_to_short").argtypes = [_d]
+            s("double_to_short").restype = C.c_short
+            s("vfo_get_publish").argtypes = [_vp, _vp, _vp, _vp, _vp]
+        else:
+            s("vfo_init").argtypes = [_vp, _i, _i, _i]
+            s("vfo_set_zmq_topic").argtypes = [_vp, C.c_char_p]
+            s("process_roots").argtypes = [_vp, _i, _vp, _i, _i]
+            s("osc_table").argtypes = [_d, _d, _l, _l, _vp]
+            s("halfband_new").restype = _vp
+            s("halfband_new").argtypes = [_i, _i]
+            s("halfband_free").argtypes = [_vp]
+            s("halfband_decimate").argtypes = [_vp, _vp, _i, _vp]
+            s("fir_run").argtypes = [_vp, _i, _vp, _vp, _i, _vp]
+            s("hilbert_run").argtypes = [_i, _i, _vp, _i, _vp]
+            s("delay_run").argtypes = [_i, _vp, _i, _vp]
+
+
+_cache: dict[str, _Lib] = {}
+
+
+def load(kind: str = "port") -> _Lib:
+    if kind not in _cache:
+        _cache[kind] = _Lib(kind)
+    return _cache[kind]
+
+
+def have_reference() -> bool:
+    return os.path.exists(REF_SO)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class OracleVfo:
+    """One VFO node of either oracle.  Method names follow vfo.h:21-38."""
+
+    def __init__(self, kind: str = "port"):
+        self.L = load(kind)
+        self.kind = kind
+        self.h = self.L.fn("vfo_new")()
+        self.children: list[OracleVfo] = []
+        self.parent: OracleVfo | None = None
+        self.topic = ""
+        self._spb = 0
+        self._late = 0
+        self._owned = True
+
+    # -- the reference's setters ------------------------------------------------
+    def setFs(self, fs):
+        self.L.fn("vfo_set_fs")(self.h, int(fs))
+
+    def setDecimationCount(self, c):
+        self.L.fn("vfo_set_decimation_count")(self.h, int(c))
+
+    def setMixerFreq(self, f):
+        self.L.fn("vfo_set_mixer_freq")(self.h, float(f))
+
+    def setDemodUSB(self, usb):
+        self.L.fn("vfo_set_demod_usb")(self.h, int(bool(usb)))
+
+    def setFilterBandwidth(self, bw):
+        self.L.fn("vfo_set_filter_bandwidth")(self.h, float(bw))
+
+    def setGain(self, g):
+        self.L.fn("vfo_set_gain")(self.h, float(g))
+
+    def setCompressonStyle(self, st):  # sic, vfo.h:36
+        self.L.fn("vfo_set_compression_style")(self.h, int(st))
+
+    def setScaleComp(self, s):
+        self.L.fn("vfo_set_scale_comp")(self.h, int(s))
+
+    def setZmqTopic(self, t):
+        self.topic = t
+        name = "vfo_set_topic" if self.kind == "port" else "vfo_set_zmq_topic"
+        self.L.fn(name)(self.h, t.encode())
+
+    def init(self, samplesPerBuffer, bind=True, lateDecimate=0):
+        self._spb, self._late = int(samplesPerBuffer), int(lateDecimate)
+        if self.kind == "port":
+            rc = self.L.fn("vfo_init")(self.h, self._spb, self._late)
+        else:
+            rc = self.L.fn("vfo_init")(self.h, self._spb, int(bool(bind)), self._late)
+        if rc != 0:
+            raise ValueError(f"vfo::init failed ({rc}): the reference throws std::out_of_range here")
+
+    def addChild(self, child: "OracleVfo"):
+        """setVFOs + push_back (mainwindow.cpp:136,225)."""
+        self.L.fn("vfo_add_child")(self.h, child.h)
+        child.parent = self
+        child._owned = False
+        self.children.append(child)
+
+    def process(self, iq):
+        iq = _f32(iq).reshape(-1)
+        self.L.fn("vfo_process")(self.h, iq.ctypes.data, iq.size // 2)
+
+    # -- observation -------------------------------------------------------------
+    @property
+    def decimateCount(self):
+        return self.L.fn("vfo_decimate_count")(self.h)
+
+    @property
+    def outputRate(self):
+        return int(self.L.fn("vfo_output_rate")(self.h))
+
+    def stream(self, stage=None):
+        """decimate[stage] as complex64 (default: the final stage)."""
+        if stage is None:
+            stage = self.decimateCount
+        n = self.L.fn("vfo_get_stream")(self.h, stage, None, 0)
+        out = np.zeros(2 * max(n, 1), np.float32)
+        self.L.fn("vfo_get_stream")(self.h, stage, out.ctypes.data, n)
+        return out[: 2 * n].view(np.complex64).copy()
+
+    def usb(self):
+        n = self.L.fn("vfo_get_usb")(self.h, None, 0)
+        out = np.zeros(max(n, 1), np.int16)
+        self.L.fn("vfo_get_usb")(self.h, out.ctypes.data, n)
+        return out[:n].copy()
+
+    def usb_prequant(self):
+        assert self.kind == "port"
+        n = self.L.fn("vfo_get_usb_prequant")(self.h, None, 0)
+        out = np.zeros(max(n, 1), np.float64)
+        self.L.fn("vfo_get_usb_prequant")(self.h, out.ctypes.data, n)
+        return out[:n].copy()
+
+    def iq(self):
+        n = self.L.fn("vfo_get_iq")(self.h, None, 0)
+        out = np.zeros(max(n, 1), np.int8)
+        self.L.fn("vfo_get_iq")(self.h, out.ctypes.data, n)
+        return out[:n].copy()
+
+    def taps(self, which):
+        out = np.zeros(4096, np.float32)
+        n = self.L.fn(f"vfo_get_{which}_taps")(self.h, out.ctypes.data, 4096)
+        return out[:n].copy()
+
+    def publish_record(self):
+        """(topic5, rate, payload bytes) as handed to ZmqPublisher::publish, or None."""
+        assert self.kind == "port"
+        topic = C.create_string_buffer(5)
+        rate, ln, ptr = C.c_uint(0), C.c_uint(0), C.c_void_p(0)
+        ok = self.L.fn("vfo_get_publish")(self.h, topic, C.byref(rate), C.byref(ptr), C.byref(ln))
+        if not ok:
+            return None
+        return topic.raw, rate.value, C.string_at(ptr.value, ln.value)
+
+    def free(self):
+        if self.h and self._owned:
+            self.L.fn("vfo_free")(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def process_roots(roots: list[OracleVfo], iq, frames=1, threads=1):
+    """sdrj::demodData's loop over the main VFOs (sdrj.cpp:288-294), `frames` times."""
+    L = roots[0].L
+    arr = (C.c_void_p * len(roots))(*[r.h for r in roots])
+    iq = _f32(iq).reshape(-1)
+    if L.kind == "port":
+        L.fn("process_roots")(arr, len(roots), iq.ctypes.data, iq.size // 2, int(frames), int(threads))
+    else:
+        L.fn("process_roots")(arr, len(roots), iq.ctypes.data, iq.size // 2, int(frames))
+
+
+# ---- primitives ---------------------------------------------------------------------------
+def osc_sequence(kind, fs, f, n):
+    out = np.zeros(2 * n, np.float32)
+    load(kind).fn("osc_sequence")(float(fs), float(f), int(n), out.ctypes.data)
+    return out.view(np.complex64)
+
+
+def osc_table(kind, fs, f):
+    n = int(fs)
+    out = np.zeros(2 * n, np.float32)
+    L = load(kind)
+    if kind == "port":
+        L.fn("osc_table")(float(fs), float(f), out.ctypes.data)
+    else:
+        L.fn("osc_table")(float(fs), float(f), 0, n, out.ctypes.data)
+    return out.view(np.complex64)
+
+
+def low_pass(kind, gain, fs, fc, tw):
+    out = np.zeros(4096, np.float32)
+    n = load(kind).fn("low_pass")(float(gain), float(fs), float(fc), float(tw), out.ctypes.data, 4096)
+    if n < 0:
+        raise ValueError("firdes check failed")
+    return out[:n].copy()
+
+
+def hilbert_taps(kind, length, fs):
+    out = np.zeros(length, np.float32)
+    load(kind).fn("hilbert_taps")(int(length), int(fs), out.ctypes.data)
+    return out
+
+
+def dc_correct(iq, state):
+    """In-place DC removal on interleaved float32 (port only; sdrj.cpp:277-283)."""
+    iq = iq.reshape(-1)
+    assert iq.dtype == np.float32 and state.dtype == np.float32
+    load("port").fn("dc_correct")(iq.ctypes.data, iq.size // 2, state.ctypes.data)
+
+
+def u8_to_float(b):
+    b = np.ascontiguousarray(b, np.uint8)
+    out = np.zeros(b.size, np.float32)
+    load("port").fn("u8_to_float")(b.ctypes.data, b.size, out.ctypes.data)
+    return out
+
+
+# ---- whole trees ------------------------------------------------------------------------------
+def build_tree(kind: str, topo):
+    """Instantiate a sdrreceiver_amd.topology.Topology on an oracle, following the order of
+    calls MainWindow makes (mainwindow.cpp:105-136,150-225).  Returns (nodes, roots)."""
+    nodes: list[OracleVfo] = []
+    for d in topo.vfos:
+        v = OracleVfo(kind)
+        v.setFs(d.fs)
+        v.setDecimationCount(d.decimate_count)
+        v.setMixerFreq(d.mixer_freq)
+        v.setDemodUSB(d.demod_usb)
+        v.setCompressonStyle(d.cstyle)
+        v.setScaleComp(d.scalecomp)
+        if d.demod_usb:
+            v.setFilterBandwidth(d.filter_bw)
+            v.setGain(d.gain)
+        if d.topic:
+            v.setZmqTopic(d.topic)
+        v.init(d.samples_per_buffer, bind=d.demod_usb, lateDecimate=d.late_decimate)
+        nodes.append(v)
+    for i, d in enumerate(topo.vfos):
+        if d.parent >= 0:
+            nodes[d.parent].addChild(nodes[i])
+    roots = [nodes[i] for i in topo.roots()]
+    return nodes, roots
