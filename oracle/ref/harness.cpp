@@ -29,6 +29,8 @@
 #include <QObject>
 #include <QString>
 #include <QVector>
+#include <QSettings>
+#include <QStringList>
 #include <zmq.h>
 
 #define private public
@@ -318,6 +320,26 @@ int ref_publish_roundtrip(const char *addr, const unsigned char *payload, unsign
     zmq_close(sub);
     zmq_ctx_term(ctx);
     return got;
+}
+
+// ---------------------------------------------------------------- INI parsing
+// What QSettings(IniFormat) -- the parser MainWindow uses (mainwindow.cpp:27) -- makes of a
+// profile: every key with its string value as "key=value\n".  Pins sdrreceiver_amd's INI parser.
+int ref_qsettings_dump(const char *path, char *out, int max)
+{
+    QSettings settings(QString::fromUtf8(path), QSettings::IniFormat);
+    QByteArray all;
+    const QStringList keys = settings.allKeys();
+    for (int i = 0; i < keys.size(); ++i) {
+        all += keys.at(i).toUtf8();
+        all += '=';
+        all += settings.value(keys.at(i)).toString().toUtf8();
+        all += '\n';
+    }
+    int n = all.size() < max - 1 ? all.size() : max - 1;
+    std::memcpy(out, all.constData(), n);
+    out[n] = 0;
+    return all.size();
 }
 
 } // extern "C"

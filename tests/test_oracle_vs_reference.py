@@ -1,0 +1,91 @@
+"""Live comparison of the plain-C oracle with the REAL reference build (oracle/_ref), where it
+exists (the build container; it also travels to the GPU box as a built .so).  Bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from helpers import REFERENCE_ROOT, bits, golden_topology
+from oracle import binding as ob
+from sdrreceiver_amd import synth, topology as tp
+
+pytestmark = pytest.mark.skipif(not ob.have_reference(), reason="oracle/_ref/libsdrref.so not built")
+
+
+def _try_reference():
+    try:
+        ob.load("reference")
+    except OSError as e:  # e.g. the Qt runtime is absent on this box
+        pytest.skip(f"reference build not loadable here: {e}")
+
+
+@pytest.mark.parametrize("key,frames", [("config1", 5), ("54w", 2), ("288k", 6), ("compress", 1)])
+def test_trees_bit_exact(key, frames):
+    _try_reference()
+    topo = golden_topology(key)
+    trees = {k: ob.build_tree(k, topo) for k in ("port", "reference")}
+    lcg = synth.Lcg(3)
+    for f in range(frames):
+        iq = synth.lcg_frame(topo.frame, lcg) + synth.tone_frame(topo.frame, topo.fs, [(-380000.0, 20.0)], f * topo.frame)
+        for k in trees:
+            ob.process_roots(trees[k][1], iq)
+        for i, v in enumerate(topo.vfos):
+            a, b = trees["port"][0][i], trees["reference"][0][i]
+            for s in range(v.decimate_count + 1):
+                assert np.array_equal(bits(a.stream(s)), bits(b.stream(s))), (key, f, i, s)
+            if not topo.children(i):
+                if v.demod_usb:
+                    assert np.array_equal(a.usb(), b.usb()), (key, f, i)
+                else:
+                    assert np.array_equal(a.iq(), b.iq()), (key, f, i)
+    for i, v in enumerate(topo.vfos):
+        a, b = trees["port"][0][i], trees["reference"][0][i]
+        assert a.outputRate == b.outputRate
+        for which in ("fir_usb", "fir_dec", "hilbert"):
+            assert np.array_equal(bits(a.taps(which)), bits(b.taps(which)))
+
+
+def test_random_designs_and_tables():
+    _try_reference()
+    rng = np.random.default_rng(5)
+    for _ in range(12):
+        fs = int(rng.choice([12000, 24000, 48000, 60000, 240000]))
+        fc = float(rng.integers(500, fs // 2))
+        tw = fc / 4
+        assert np.array_equal(bits(ob.low_pass("port", 2, fs, fc, tw)), bits(ob.low_pass("reference", 2, fs, fc, tw)))
+    for fs, f in [(48000, 1234), (96000, -47999), (12000, 5999), (24000, -1)]:
+        assert np.array_equal(bits(ob.osc_table("port", fs, f)), bits(ob.osc_table("reference", fs, f)))
+    for n in (100, 3000, 12000):
+        assert np.array_equal(bits(ob.hilbert_taps("port", 125, n)), bits(ob.hilbert_taps("reference", 125, n)))
+
+
+def test_fir_newest_sample_excluded():
+    """FIR::FIRUpdateAndProcess (dsp.cpp:59-71) sums the N samples BEFORE the newest one."""
+    _try_reference()
+    R = ob.load("reference")
+    taps = np.array([1, 10, 100], np.float32)
+    x = np.array([1, 2, 3, 4, 5], np.float32)
+    y = np.zeros(5, np.float32)
+    R.fn("fir_run")(taps.ctypes.data, 3, x.ctypes.data, None, 5, y.ctypes.data)
+    # y[m] = 1*x[m-3] + 10*x[m-2] + 100*x[m-1]
+    assert list(y) == [0, 100, 210, 321, 432]
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_ROOT), reason="needs the reference's sample INIs")
+def test_ini_parser_matches_qsettings():
+    _try_reference()
+    R = ob.load("reference")
+    fn = R.fn("qsettings_dump")
+    fn.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    ini_dir = os.path.join(REFERENCE_ROOT, "sample_ini")
+    for name in sorted(os.listdir(ini_dir)):
+        path = os.path.join(ini_dir, name)
+        buf = C.create_string_buffer(1 << 20)
+        fn(path.encode(), buf, 1 << 20)
+        qs = dict(line.split("=", 1) for line in buf.value.decode().splitlines() if "=" in line)
+        mine = tp.parse_ini(open(path, encoding="utf-8", errors="replace").read())
+        keys = [k for k in qs if not k.startswith("#") and "/#" not in k]
+        assert keys, name
+        for k in keys:
+            assert mine.get(k) == qs[k], (name, k, mine.get(k), qs[k])
