@@ -1,0 +1,155 @@
+/* include/sdrx.h -- C ABI of the MI355X-native per-VFO IQ chain (libsdrx.so).
+ *
+ * Drop-in boundary for ONE path of jeroenbeijer/SDRReceiver: the per-VFO chain
+ *   table-NCO complex mix -> cascaded 11-tap half-band decimation -> USB demodulation
+ *   (62-sample delay minus 125-tap Hilbert) -> optional Hamming low-pass -> int16
+ * i.e. the arithmetic of vfo.cpp / oscillator.cpp / halfbanddecimator.cpp / jonti/dsp.cpp /
+ * gnuradio/firfilter.cpp.  Everything around it (Qt GUI, RTL-SDR / rtl_tcp ingest, the ZeroMQ
+ * socket) stays on the host side of this boundary; INTEGRATION.md shows the reference-side
+ * binding.  All citations are file:line in the reference repository.
+ *
+ * Conventions: plain C types only, every function returns 0 on success and a negative
+ * SDRX_E* code on failure (no exception crosses the ABI; sdrx_last_error() has the text).
+ * A context is single-caller and not re-entrant -- like the reference, where all VFOs run on
+ * one thread (sdrj.cpp:288-294).  There is no CPU fallback: without a usable HIP device
+ * sdrx_create() fails.
+ */
+#ifndef SDRX_H
+#define SDRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDRX_ABI_VERSION 1
+
+enum {
+    SDRX_OK = 0,
+    SDRX_EINVAL = -1,   /* bad argument / bad descriptor                               */
+    SDRX_ESTATE = -2,   /* call order violated (e.g. process before finalize)            */
+    SDRX_EFILTER = -3,  /* tap design rejected: where the reference throws out_of_range  */
+                        /* from firfilter::sanity_check_1f (firfilter.cpp:122-134)       */
+    SDRX_EHIP = -4,     /* HIP runtime error                                             */
+    SDRX_EUNSUPPORTED = -5, /* geometry outside what the kernels handle (see sdrx_finalize) */
+    SDRX_ENOMEM = -6
+};
+
+typedef struct sdrx_ctx sdrx_ctx;
+
+/* One VFO node.  Each field replaces one reference setter; sdrx_add_vfo + sdrx_finalize
+ * together replace `new vfo` + setters + vfo::init (vfo.cpp:60-176, called from
+ * mainwindow.cpp:105-136 for main VFOs and 150-225 for sub VFOs). */
+typedef struct sdrx_vfo_desc {
+    int32_t fs;                 /* vfo::setFs                 vfo.cpp:189-193: input rate of THIS vfo */
+    int32_t decimate_count;     /* vfo::setDecimationCount    vfo.cpp:194-197: half-band stages, 0..8 */
+    double mixer_freq_hz;       /* vfo::setMixerFreq          vfo.cpp:199-204: integer Hz, may be < 0 */
+    int32_t demod_usb;          /* vfo::setDemodUSB           vfo.cpp:468-472: 1 = USB audio leaf      */
+    int32_t late_decimate;      /* vfo::init(..,lateDecimate) vfo.cpp:70-101: 0, 5 or 6               */
+    int32_t filter_bw_hz;       /* vfo::setFilterBandwidth    vfo.cpp:223-227: 0 = no audio low-pass   */
+    float gain;                 /* vfo::setGain               vfo.cpp:229-233                          */
+    int32_t cstyle;             /* vfo::setCompressonStyle    vfo.cpp:455-460 (compress(), 389-424)    */
+    int32_t scalecomp;          /* vfo::setScaleComp          vfo.cpp:462-467                          */
+    int32_t parent_id;          /* vfo::setVFOs on the parent vfo.cpp:485-490; -1 = fed by the raw     */
+                                /*   stream, i.e. a member of sdrj's main-VFO list (sdrj.cpp:288-294)  */
+    int32_t samples_per_buffer; /* vfo::init(samplesPerBuffer) vfo.cpp:60: complex samples per frame   */
+    char topic[8];              /* vfo::setZmqTopic: the first 5 bytes go on the wire                  */
+                                /*   (zmqpublisher.cpp:91)                                              */
+} sdrx_vfo_desc;
+
+/* Replaces the call `ZmqPublisher::publish(buf, len, topic, sampleRate)` made by
+ * vfo::transmitData (vfo.cpp:426-453, zmqpublisher.h:16).  Invoked once per publishing leaf per
+ * frame, in the reference's order: main VFOs in list order, their sub VFOs in list order
+ * (sdrj.cpp:288-294, vfo.cpp:257-263).  `buf` is owned by the library and valid until the next
+ * sdrx_process*()/sdrx_destroy().  Not invoked for an empty payload (zmqpublisher.cpp:88). */
+typedef void (*sdrx_publish_fn)(void *user, const char topic[5], uint32_t sample_rate, const void *buf,
+                                uint32_t len_bytes);
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int sdrx_abi_version(void);
+int sdrx_create(sdrx_ctx **ctx, int device_ordinal);
+int sdrx_destroy(sdrx_ctx *ctx);
+const char *sdrx_last_error(const sdrx_ctx *ctx); /* ctx may be NULL: error of a failed create */
+
+/* ---- configuration ( = MainWindow building the VFO tree) ------------------------------------ */
+int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
+/* Options, all before sdrx_finalize:
+ *   "exact"  1 (default): every fp32 operation rounded like the reference's -O2 x86-64 build
+ *            (no FMA contraction, reference summation order) -> results bit-identical to it.
+ *            0: FMA and tree-order dot products; within 1e-6 relative of the reference.
+ *   "keep_prequant" 1: also keep the pre-quantisation float `usb*gain*32768` per leaf
+ *            (parity tests; sdrx_get_prequant).   default 0
+ *   "segments" n: force n time-segments per VFO-frame in the decimation kernel (0 = auto). */
+int sdrx_set_option(sdrx_ctx *ctx, const char *name, int value);
+/* All of vfo::init for every node: NCO tables (oscillator.cpp:4-32), low-pass designs
+ * (firfilter.cpp:64-119), Hilbert taps (dsp.cpp:184-217), zeroed filter state, buffers.
+ * SDRX_EFILTER where the reference would throw; SDRX_EUNSUPPORTED unless for every node
+ * fs % 16 == 0, samples_per_buffer % 16 == 0 and samples_per_buffer % 2^decimate_count == 0
+ * (true for every rate the reference accepts, mainwindow.h:29), and a child's
+ * samples_per_buffer equals its parent's samples_per_buffer / 2^decimate_count. */
+int sdrx_finalize(sdrx_ctx *ctx);
+int sdrx_set_publish_callback(sdrx_ctx *ctx, sdrx_publish_fn fn, void *user);
+
+/* ---- per frame ( = sdrj::demodData, sdrj.cpp:266-305) ---------------------------------------- */
+/* `iq`: n_complex interleaved (I,Q) float pairs on the HOST, as sdr::audio_signal_out /
+ * sdrj::readyRead deliver them (values b-127, jonti/sdr.cpp:43-49).  n_complex must equal the
+ * samples_per_buffer of the parent-less VFOs.  Synchronous: on return every payload is in host
+ * memory and the publish callback has run for every leaf.  The DC-bias IIR of sdrj.cpp:271-286
+ * stays on the caller's side of this entry point (or use sdrx_process_u8). */
+int sdrx_process(sdrx_ctx *ctx, const float *iq, int n_complex);
+/* Raw dongle bytes (2 per complex sample, unsigned, offset 127) with the byte->float LUT
+ * (jonti/sdr.cpp:43-49,122-129; sdrj.cpp:155-160) and, if correct_dc != 0, the DC-bias IIR
+ * (sdrj.cpp:271-286) done on the device.  Otherwise like sdrx_process. */
+int sdrx_process_u8(sdrx_ctx *ctx, const uint8_t *iq_bytes, int n_complex, int correct_dc);
+
+/* Device-resident variant for pipelines that already hold the frame in HBM (bench.py, the
+ * multi-GPU path where the frame arrives by RCCL broadcast): `dev_iq` is a DEVICE pointer to
+ * n_complex cf32.  Asynchronous on the context's stream; sdrx_fetch() waits, copies the payloads
+ * to the host and runs the callbacks; sdrx_sync() only waits. */
+int sdrx_process_device(sdrx_ctx *ctx, const void *dev_iq, int n_complex);
+int sdrx_fetch(sdrx_ctx *ctx);
+int sdrx_sync(sdrx_ctx *ctx);
+/* Run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the context's
+ * own; NULL restores the default. */
+int sdrx_set_stream(sdrx_ctx *ctx, void *hip_stream);
+
+/* ---- results -------------------------------------------------------------------------------- */
+/* Payload of leaf `id` after the last frame: int16 audio (USB leaf) or packed int8 IQ
+ * (compress(), vfo.cpp:389-424).  *rate = outputRate (vfo.cpp:102). */
+int sdrx_get_output(sdrx_ctx *ctx, int id, const void **buf, uint32_t *len_bytes, uint32_t *rate);
+/* decimate[decimateCount] of node `id` (public member vfo.h:39 -- what the fftData signal
+ * carries, vfo.cpp:290-293): copies up to max_complex cf32 to `out`, returns the count in *n. */
+int sdrx_get_stream(sdrx_ctx *ctx, int id, float *out_iq, int max_complex, int *n);
+int sdrx_get_prequant(sdrx_ctx *ctx, int id, float *out, int max, int *n);
+/* Designed tap sets, for parity checks: which = 0 audio low-pass, 1 late-decimation low-pass,
+ * 2 Hilbert. */
+int sdrx_get_taps(sdrx_ctx *ctx, int id, int which, float *out, int max, int *n);
+/* NCO table entries [first, first+count) of node `id` as the device generated them. */
+int sdrx_get_nco(sdrx_ctx *ctx, int id, long first, long count, float *out_iq);
+
+/* ---- introspection / measurement ------------------------------------------------------------- */
+typedef struct sdrx_stats {
+    int32_t n_vfos, n_leaves, n_levels;
+    int32_t exact;
+    int64_t algorithmic_bytes_per_frame; /* sum of 8*n_in + W_out              */
+    int64_t vfo_samples_per_frame;       /* sum of n_in over all VFOs                        */
+    int64_t device_bytes;                /* HBM allocated by this context                    */
+    int64_t frames;                      /* frames processed so far                          */
+} sdrx_stats;
+int sdrx_get_stats(sdrx_ctx *ctx, sdrx_stats *out);
+/* Per-kernel GPU time from HIP events recorded on the launch stream.  enable=1 brackets every
+ * kernel launch with events (small overhead: use for profiling runs, not for throughput runs).
+ * sdrx_get_kernel_times: accumulated milliseconds and launch counts since enabling, for
+ * kernel kinds 0..SDRX_NKERNELS-1 (names from sdrx_kernel_name). */
+#define SDRX_NKERNELS 6
+int sdrx_enable_kernel_timing(sdrx_ctx *ctx, int enable);
+int sdrx_get_kernel_times(sdrx_ctx *ctx, double ms[SDRX_NKERNELS], int64_t launches[SDRX_NKERNELS],
+                          int64_t alg_bytes[SDRX_NKERNELS]);
+const char *sdrx_kernel_name(int kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRX_H */

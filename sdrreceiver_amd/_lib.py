@@ -1,0 +1,90 @@
+"""ctypes binding of libsdrx.so (include/sdrx.h).  There is no fallback: if the HIP library is
+missing or cannot be loaded this module raises, and without a GPU ``sdrx_create`` fails."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdrx.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+NKERNELS = 6
+
+
+class VfoDescC(C.Structure):
+    """struct sdrx_vfo_desc"""
+    _fields_ = [
+        ("fs", C.c_int32), ("decimate_count", C.c_int32), ("mixer_freq_hz", C.c_double),
+        ("demod_usb", C.c_int32), ("late_decimate", C.c_int32), ("filter_bw_hz", C.c_int32),
+        ("gain", C.c_float), ("cstyle", C.c_int32), ("scalecomp", C.c_int32), ("parent_id", C.c_int32),
+        ("samples_per_buffer", C.c_int32), ("topic", C.c_char * 8),
+    ]
+
+
+class StatsC(C.Structure):
+    """struct sdrx_stats"""
+    _fields_ = [
+        ("n_vfos", C.c_int32), ("n_leaves", C.c_int32), ("n_levels", C.c_int32), ("exact", C.c_int32),
+        ("algorithmic_bytes_per_frame", C.c_int64), ("vfo_samples_per_frame", C.c_int64),
+        ("device_bytes", C.c_int64), ("frames", C.c_int64),
+    ]
+
+
+PUBLISH_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_char), C.c_uint32, C.c_void_p, C.c_uint32)
+
+# every symbol include/sdrx.h declares: (restype, argtypes)
+_vp, _i = C.c_void_p, C.c_int
+SYMBOLS = {
+    "sdrx_abi_version": (_i, []),
+    "sdrx_create": (_i, [C.POINTER(_vp), _i]),
+    "sdrx_destroy": (_i, [_vp]),
+    "sdrx_last_error": (C.c_char_p, [_vp]),
+    "sdrx_add_vfo": (_i, [_vp, C.POINTER(VfoDescC), C.POINTER(_i)]),
+    "sdrx_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "sdrx_finalize": (_i, [_vp]),
+    "sdrx_set_publish_callback": (_i, [_vp, PUBLISH_FN, _vp]),
+    "sdrx_process": (_i, [_vp, _vp, _i]),
+    "sdrx_process_u8": (_i, [_vp, _vp, _i, _i]),
+    "sdrx_process_device": (_i, [_vp, _vp, _i]),
+    "sdrx_fetch": (_i, [_vp]),
+    "sdrx_sync": (_i, [_vp]),
+    "sdrx_set_stream": (_i, [_vp, _vp]),
+    "sdrx_get_output": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "sdrx_get_stream": (_i, [_vp, _i, _vp, _i, C.POINTER(_i)]),
+    "sdrx_get_prequant": (_i, [_vp, _i, _vp, _i, C.POINTER(_i)]),
+    "sdrx_get_taps": (_i, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
+    "sdrx_get_nco": (_i, [_vp, _i, C.c_long, C.c_long, _vp]),
+    "sdrx_get_stats": (_i, [_vp, C.POINTER(StatsC)]),
+    "sdrx_enable_kernel_timing": (_i, [_vp, _i]),
+    "sdrx_get_kernel_times": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "sdrx_kernel_name": (C.c_char_p, [_i]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of libsdrx.so, in-tree (sdrreceiver_amd/csrc/Makefile)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-C", CSRC], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """The loaded library.  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: the HIP extension must be built "
+                              f"(python -c 'import __graft_entry__ as g; g.build()' or make -C {CSRC}); "
+                              "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)  # AttributeError if the header and the library ever diverge
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib

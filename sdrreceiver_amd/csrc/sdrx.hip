@@ -1,0 +1,964 @@
+// sdrx.hip -- host side of libsdrx.so: the C ABI of include/sdrx.h, VFO-tree bookkeeping,
+// HBM layout, and the per-frame launch sequence.  The arithmetic lives in kernels.hip.
+//
+// Data layout in HBM (all in one arena, zeroed at finalize == the reference's zero start state):
+//   per VFO   NCO checkpoints  (L/16+1) cf32           cp[j] = table[16j-1]
+//             half-band state  2 x d x 10 cf32         ping-pong by frame parity
+//             stream           2 x (H + n/2^d) cf32    decimate[d] of the current frame behind H
+//                                                       history samples of the previous frame
+//                                                       (H = 0 for VFOs that only feed children)
+//             late-dec stream  2 x (H' + n_out) cf32   only for lateDecimate leaves
+//   per leaf  payload          n_out int16 | n (or 2n) int8, packed in one buffer => one D2H copy
+// Frame f reads state[f&1] and writes state[(f+1)&1]; nothing is copied between frames.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/sdrx.h"
+#include "kernels.hip"
+#include "tapdesign.h"
+
+using namespace sdrx;
+
+static_assert(sizeof(sdrx_vfo_desc) == 56 && offsetof(sdrx_vfo_desc, topic) == 48, "sdrx_vfo_desc ABI layout");
+static_assert(sizeof(sdrx_stats) == 48, "sdrx_stats ABI layout");
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum Kind { KIND_MIX_ROOT = 0, KIND_MIX_SUB = 1, KIND_LATE_DEC = 2, KIND_DEMOD = 3, KIND_COMPRESS = 4, KIND_INGEST = 5 };
+const char *kKindNames[SDRX_NKERNELS] = {"k_mix_decimate(level0)", "k_mix_decimate(sub)", "k_late_decimate",
+                                         "k_usb_demod",            "k_compress",          "k_ingest"};
+
+struct Node {
+    sdrx_vfo_desc d;
+    std::vector<int> children;
+    int level = 0;
+    int n_f = 0;       // samples of decimate[d] per frame
+    int n_out = 0;     // after late decimation
+    unsigned rate = 0; // outputRate
+    bool leaf = false;
+    // designed taps (host copies for sdrx_get_taps)
+    std::vector<float> lpf, dec, hilbert;
+    // device placement (byte offsets into the arena)
+    size_t off_cp = 0, off_hb[2] = {0, 0}, off_stream[2] = {0, 0}, off_z[2] = {0, 0}, off_preq = 0;
+    size_t off_lpf = 0, off_dec = 0, off_hilbert = 0;
+    int H = 0, Hx = 0;
+    size_t pay_off = 0; // into the payload buffer
+    uint32_t pay_len = 0;
+    float rot_re = 0, rot_im = 0;
+};
+
+struct Launch1 { // one k_mix_decimate launch (a tree level)
+    int kind;
+    int n_work;
+    int lds_bytes;
+    size_t off_work; // arena offset of K1Work[]
+    int64_t alg_bytes;
+};
+struct LaunchB { // block-per-256-outputs launches (late decimate / demod / compress)
+    int kind;
+    int n_vfo, blocks_per_vfo;
+    size_t off_desc;
+    int lds_bytes;
+    int64_t alg_bytes;
+};
+
+struct TimedEvent {
+    hipEvent_t a, b;
+    int kind;
+    int64_t bytes;
+};
+
+} // namespace
+
+struct sdrx_ctx {
+    int device = 0;
+    std::string err;
+    std::vector<Node> nodes;
+    bool finalized = false;
+    int opt_exact = 1, opt_prequant = 0, opt_segments = 0;
+    sdrx_publish_fn cb = nullptr;
+    void *cb_user = nullptr;
+
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    unsigned char *arena = nullptr;
+    size_t arena_bytes = 0;
+    unsigned char *d_pay = nullptr, *h_pay = nullptr;
+    size_t pay_bytes = 0;
+    float2 *d_raw = nullptr; // staging for host-fed frames
+    unsigned char *d_raw_u8 = nullptr;
+    float *d_dc_state = nullptr;
+    size_t raw_cap = 0;
+    int root_frame = 0; // samples_per_buffer of the parent-less VFOs
+    size_t off_k1vfo = 0;
+    std::vector<Launch1> l1;
+    std::vector<LaunchB> lb;
+    std::vector<int> publish_order;
+    unsigned long long frame_no = 0;
+    bool pending_fetch = false;
+    int64_t alg_bytes = 0, vfo_samples = 0;
+    int n_levels = 0;
+
+    bool timing = false;
+    std::vector<TimedEvent> pending_events;
+    std::vector<hipEvent_t> event_pool;
+    double t_ms[SDRX_NKERNELS] = {0};
+    int64_t t_n[SDRX_NKERNELS] = {0};
+    int64_t t_bytes[SDRX_NKERNELS] = {0};
+};
+
+namespace {
+
+int fail(sdrx_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c)
+        c->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((c), SDRX_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct ArenaPlan {
+    size_t size = 0;
+    size_t take(size_t bytes)
+    {
+        size_t o = align_up(size, 256);
+        size = o + bytes;
+        return o;
+    }
+};
+
+int warmup_chunks(int d)
+{
+    // A segment that starts mid-frame starts from zero state.  Stage s's 16-sample carry is
+    // made of real samples again once 26 * 2^s input samples have gone by (10 * (2^s - 1) until
+    // its inputs are valid + 16 of them), so run that many whole chunks before emitting.
+    if (d <= 0)
+        return 0;
+    return (26 * (1 << (d - 1)) + kChunk - 1) / kChunk;
+}
+
+hipEvent_t get_event(sdrx_ctx *c)
+{
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void drain_events(sdrx_ctx *c)
+{
+    for (auto &te : c->pending_events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, te.a, te.b) == hipSuccess) {
+            c->t_ms[te.kind] += ms;
+            c->t_n[te.kind] += 1;
+            c->t_bytes[te.kind] += te.bytes;
+        }
+        c->event_pool.push_back(te.a);
+        c->event_pool.push_back(te.b);
+    }
+    c->pending_events.clear();
+}
+
+struct Bracket { // RAII: event pair around one launch when timing is on
+    sdrx_ctx *c;
+    TimedEvent te{};
+    bool on;
+    Bracket(sdrx_ctx *ctx, int kind, int64_t bytes) : c(ctx), on(ctx->timing)
+    {
+        if (!on)
+            return;
+        te.kind = kind;
+        te.bytes = bytes;
+        te.a = get_event(c);
+        te.b = get_event(c);
+        (void)hipEventRecord(te.a, c->stream);
+    }
+    ~Bracket()
+    {
+        if (!on)
+            return;
+        (void)hipEventRecord(te.b, c->stream);
+        c->pending_events.push_back(te);
+    }
+};
+
+template <bool EXACT>
+int enqueue_frame(sdrx_ctx *c, const float2 *raw)
+{
+    const K1Vfo *k1 = reinterpret_cast<const K1Vfo *>(c->arena + c->off_k1vfo);
+    for (const Launch1 &L : c->l1) {
+        Bracket b(c, L.kind, L.alg_bytes);
+        hipLaunchKernelGGL(k_mix_decimate<EXACT>, dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1,
+                           reinterpret_cast<const K1Work *>(c->arena + L.off_work), raw, c->frame_no);
+    }
+    for (const LaunchB &L : c->lb) {
+        Bracket b(c, L.kind, L.alg_bytes);
+        const dim3 grid(L.n_vfo * L.blocks_per_vfo);
+        if (L.kind == KIND_LATE_DEC)
+            hipLaunchKernelGGL(k_late_decimate<EXACT>, grid, dim3(256), L.lds_bytes, c->stream,
+                               reinterpret_cast<const K2aVfo *>(c->arena + L.off_desc), L.blocks_per_vfo, c->frame_no);
+        else if (L.kind == KIND_DEMOD)
+            hipLaunchKernelGGL(k_usb_demod<EXACT>, grid, dim3(256), 0, c->stream,
+                               reinterpret_cast<const K2Vfo *>(c->arena + L.off_desc), L.blocks_per_vfo, c->frame_no);
+        else
+            hipLaunchKernelGGL(k_compress, grid, dim3(256), 0, c->stream,
+                               reinterpret_cast<const K3Vfo *>(c->arena + L.off_desc), L.blocks_per_vfo, c->frame_no);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(c, SDRX_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    c->frame_no++;
+    c->pending_fetch = true;
+    return SDRX_OK;
+}
+
+int ensure_raw(sdrx_ctx *c, size_t n_complex)
+{
+    if (c->raw_cap >= n_complex)
+        return SDRX_OK;
+    if (c->d_raw)
+        (void)hipFree(c->d_raw);
+    if (c->d_raw_u8)
+        (void)hipFree(c->d_raw_u8);
+    HIPCHK(c, hipMalloc(&c->d_raw, n_complex * sizeof(float2)));
+    HIPCHK(c, hipMalloc(&c->d_raw_u8, n_complex * 2));
+    c->raw_cap = n_complex;
+    return SDRX_OK;
+}
+
+} // namespace
+
+// ================================================================================ C ABI
+extern "C" {
+
+int sdrx_abi_version(void) { return SDRX_ABI_VERSION; }
+
+const char *sdrx_last_error(const sdrx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+const char *sdrx_kernel_name(int kind) { return kind >= 0 && kind < SDRX_NKERNELS ? kKindNames[kind] : ""; }
+
+int sdrx_create(sdrx_ctx **out, int device)
+{
+    if (!out)
+        return fail(nullptr, SDRX_EINVAL, "sdrx_create: null output pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SDRX_EHIP, "sdrx_create: no HIP device (%s); libsdrx has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, SDRX_EINVAL, "sdrx_create: device %d out of range (0..%d)", device, ndev - 1);
+    e = hipSetDevice(device);
+    if (e != hipSuccess)
+        return fail(nullptr, SDRX_EHIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    sdrx_ctx *c = new sdrx_ctx();
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(nullptr, SDRX_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return SDRX_OK;
+}
+
+int sdrx_destroy(sdrx_ctx *c)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drain_events(c);
+    for (hipEvent_t e : c->event_pool)
+        (void)hipEventDestroy(e);
+    if (c->arena)
+        (void)hipFree(c->arena);
+    if (c->d_pay)
+        (void)hipFree(c->d_pay);
+    if (c->h_pay)
+        (void)hipHostFree(c->h_pay);
+    if (c->d_raw)
+        (void)hipFree(c->d_raw);
+    if (c->d_raw_u8)
+        (void)hipFree(c->d_raw_u8);
+    if (c->d_dc_state)
+        (void)hipFree(c->d_dc_state);
+    if (c->own_stream)
+        (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return SDRX_OK;
+}
+
+int sdrx_set_option(sdrx_ctx *c, const char *name, int value)
+{
+    if (!c || !name)
+        return SDRX_EINVAL;
+    if (c->finalized)
+        return fail(c, SDRX_ESTATE, "sdrx_set_option after sdrx_finalize");
+    if (!strcmp(name, "exact"))
+        c->opt_exact = value != 0;
+    else if (!strcmp(name, "keep_prequant"))
+        c->opt_prequant = value != 0;
+    else if (!strcmp(name, "segments"))
+        c->opt_segments = value < 0 ? 0 : value;
+    else
+        return fail(c, SDRX_EINVAL, "unknown option '%s'", name);
+    return SDRX_OK;
+}
+
+int sdrx_add_vfo(sdrx_ctx *c, const sdrx_vfo_desc *d, int *id_out)
+{
+    if (!c || !d)
+        return SDRX_EINVAL;
+    if (c->finalized)
+        return fail(c, SDRX_ESTATE, "sdrx_add_vfo after sdrx_finalize");
+    const int id = (int)c->nodes.size();
+    if (d->parent_id >= id || d->parent_id < -1)
+        return fail(c, SDRX_EINVAL, "vfo %d: parent_id %d must name an earlier vfo or be -1", id, d->parent_id);
+    if (d->decimate_count < 0 || d->decimate_count > kMaxStages)
+        return fail(c, SDRX_EINVAL, "vfo %d: decimate_count %d outside 0..8 (vfo.h:63)", id, d->decimate_count);
+    if (d->fs <= 0 || d->samples_per_buffer <= 0)
+        return fail(c, SDRX_EINVAL, "vfo %d: fs and samples_per_buffer must be positive", id);
+    if (d->late_decimate < 0 || d->late_decimate == 1)
+        return fail(c, SDRX_EINVAL, "vfo %d: late_decimate must be 0 or >= 2 (the reference uses 5 and 6)", id);
+    if (d->parent_id >= 0 && c->nodes[(size_t)d->parent_id].d.demod_usb)
+        return fail(c, SDRX_EINVAL, "vfo %d: parent %d is a USB leaf", id, d->parent_id);
+    Node n;
+    n.d = *d;
+    c->nodes.push_back(n);
+    if (d->parent_id >= 0)
+        c->nodes[(size_t)d->parent_id].children.push_back(id);
+    if (id_out)
+        *id_out = id;
+    return SDRX_OK;
+}
+
+int sdrx_set_publish_callback(sdrx_ctx *c, sdrx_publish_fn fn, void *user)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    c->cb = fn;
+    c->cb_user = user;
+    return SDRX_OK;
+}
+
+int sdrx_finalize(sdrx_ctx *c)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    if (c->finalized)
+        return fail(c, SDRX_ESTATE, "sdrx_finalize called twice");
+    if (c->nodes.empty())
+        return fail(c, SDRX_ESTATE, "sdrx_finalize: no VFOs");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int N = (int)c->nodes.size();
+
+    // ---- per-node derived quantities: everything vfo::init computes (vfo.cpp:60-176)
+    c->root_frame = 0;
+    int max_level = 0;
+    for (int i = 0; i < N; ++i) {
+        Node &n = c->nodes[(size_t)i];
+        const sdrx_vfo_desc &d = n.d;
+        n.leaf = n.children.empty();
+        if (d.fs % kRun || d.samples_per_buffer % kRun || d.fs < kChunk)
+            return fail(c, SDRX_EUNSUPPORTED, "vfo %d: fs (%d) and samples_per_buffer (%d) must be multiples of 16 and fs >= 1024", i,
+                        d.fs, d.samples_per_buffer);
+        if (d.samples_per_buffer % (1 << d.decimate_count))
+            return fail(c, SDRX_EUNSUPPORTED, "vfo %d: samples_per_buffer %d not a multiple of 2^%d", i, d.samples_per_buffer,
+                        d.decimate_count);
+        if ((long long)d.samples_per_buffer > (long long)d.fs)
+            return fail(c, SDRX_EUNSUPPORTED, "vfo %d: a frame longer than one second of signal is not supported", i);
+        n.n_f = d.samples_per_buffer >> d.decimate_count;
+        int target = (int)(d.fs / std::pow(2, d.decimate_count)); // vfo.cpp:66
+        n.n_out = n.n_f;
+        const bool late = d.demod_usb && d.late_decimate > 0; // vfo.cpp:70
+        if (late) {
+            if (n.n_f % d.late_decimate)
+                return fail(c, SDRX_EUNSUPPORTED, "vfo %d: %d samples per frame is not a multiple of late_decimate %d", i, n.n_f,
+                            d.late_decimate);
+            target /= d.late_decimate;
+            n.n_out = n.n_f / d.late_decimate;
+            if (!design_low_pass(2, (double)target * d.late_decimate, (double)(target / 2),
+                                 (double)target / (d.late_decimate - 1), n.dec)) // vfo.cpp:82-87
+                return fail(c, SDRX_EFILTER, "vfo %d: late-decimation low-pass rejected (firfilter.cpp:122-134)", i);
+            if ((int)n.dec.size() > kMaxFir)
+                return fail(c, SDRX_EUNSUPPORTED, "vfo %d: %zu-tap late-decimation filter exceeds %d", i, n.dec.size(), kMaxFir);
+        }
+        n.rate = (unsigned)target;
+        if (d.demod_usb && d.filter_bw_hz > 0) { // vfo.cpp:106-124
+            if (!design_low_pass(2, (double)target, (double)d.filter_bw_hz, (double)d.filter_bw_hz / 4, n.lpf))
+                return fail(c, SDRX_EFILTER, "vfo %d: filter_bw %d Hz rejected at %d S/s (firfilter.cpp:122-134)", i, d.filter_bw_hz,
+                            target);
+            if ((int)n.lpf.size() > kMaxFir)
+                return fail(c, SDRX_EUNSUPPORTED, "vfo %d: %zu-tap audio filter exceeds %d", i, n.lpf.size(), kMaxFir);
+        }
+        if (d.demod_usb)
+            design_hilbert(kHilbert, n.n_out, n.hilbert); // vfo.cpp:137: "Fs" = samplesOut
+        nco_rotation((double)d.fs, d.mixer_freq_hz, n.rot_re, n.rot_im);
+        if (d.parent_id < 0) {
+            n.level = 0;
+            if (c->root_frame == 0)
+                c->root_frame = d.samples_per_buffer;
+            else if (c->root_frame != d.samples_per_buffer)
+                return fail(c, SDRX_EINVAL, "vfo %d: all parent-less VFOs must share samples_per_buffer", i);
+        } else {
+            const Node &p = c->nodes[(size_t)d.parent_id];
+            n.level = p.level + 1;
+            if (d.samples_per_buffer != p.n_f)
+                return fail(c, SDRX_EUNSUPPORTED, "vfo %d: samples_per_buffer %d != parent's output frame %d", i,
+                            d.samples_per_buffer, p.n_f);
+        }
+        if (!n.leaf && d.demod_usb)
+            return fail(c, SDRX_EINVAL, "vfo %d has children but demod_usb set", i);
+        max_level = std::max(max_level, n.level);
+    }
+    c->n_levels = max_level + 1;
+
+    // ---- arena plan
+    ArenaPlan plan;
+    std::map<std::vector<float>, size_t> tap_offsets; // identical tap sets are stored once
+    auto place_taps = [&](const std::vector<float> &t) -> size_t {
+        auto it = tap_offsets.find(t);
+        if (it != tap_offsets.end())
+            return it->second;
+        size_t o = plan.take(t.size() * sizeof(float));
+        tap_offsets.emplace(t, o);
+        return o;
+    };
+    c->off_k1vfo = plan.take(sizeof(K1Vfo) * (size_t)N);
+    size_t pay = 0;
+    c->alg_bytes = 0;
+    c->vfo_samples = 0;
+    for (int i = 0; i < N; ++i) {
+        Node &n = c->nodes[(size_t)i];
+        const sdrx_vfo_desc &d = n.d;
+        const bool late = d.demod_usb && d.late_decimate > 0;
+        n.off_cp = plan.take(sizeof(float2) * (size_t)(d.fs / kRun + 1));
+        for (int p = 0; p < 2; ++p)
+            n.off_hb[p] = plan.take(sizeof(float2) * (size_t)std::max(1, d.decimate_count * kHbHist));
+        n.H = n.Hx = 0;
+        if (n.leaf && d.demod_usb) {
+            const int Hdemod = (int)align_up((size_t)(n.lpf.size() + kHilbert - 1), 4);
+            if (late) {
+                n.Hx = (int)align_up(n.dec.size(), 4);
+                n.H = Hdemod;
+            } else {
+                n.Hx = Hdemod; // the stream itself feeds the demodulator
+            }
+        }
+        for (int p = 0; p < 2; ++p)
+            n.off_stream[p] = plan.take(sizeof(float2) * (size_t)(n.Hx + n.n_f));
+        if (late)
+            for (int p = 0; p < 2; ++p)
+                n.off_z[p] = plan.take(sizeof(float2) * (size_t)(n.H + n.n_out));
+        if (!n.lpf.empty())
+            n.off_lpf = place_taps(n.lpf);
+        if (!n.dec.empty())
+            n.off_dec = place_taps(n.dec);
+        if (!n.hilbert.empty())
+            n.off_hilbert = place_taps(n.hilbert);
+        if (n.leaf) {
+            n.pay_off = pay;
+            if (d.demod_usb)
+                n.pay_len = (uint32_t)(n.n_out * 2);
+            else
+                n.pay_len = (uint32_t)(d.cstyle == 1 ? n.n_f : 2 * n.n_f); // vfo.cpp:143-150
+            pay = align_up(pay + n.pay_len, 64);
+            if (c->opt_prequant && d.demod_usb)
+                n.off_preq = plan.take(sizeof(float) * (size_t)n.n_out);
+        }
+        // SURVEY.md 8d algorithmic bytes: cf32 consumed + what this VFO hands on
+        c->alg_bytes += 8ll * d.samples_per_buffer + (n.leaf ? (int64_t)n.pay_len : 8ll * n.n_f);
+        c->vfo_samples += d.samples_per_buffer;
+    }
+
+    // ---- work lists for k_mix_decimate, one launch per tree level
+    std::vector<std::vector<K1Work>> works((size_t)c->n_levels);
+    std::vector<int> level_count((size_t)c->n_levels, 0), level_maxd((size_t)c->n_levels, 0);
+    for (const Node &n : c->nodes) {
+        level_count[(size_t)n.level]++;
+        level_maxd[(size_t)n.level] = std::max(level_maxd[(size_t)n.level], n.d.decimate_count);
+    }
+    int ncu = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+            ncu = prop.multiProcessorCount;
+    }
+    for (int i = 0; i < N; ++i) {
+        const Node &n = c->nodes[(size_t)i];
+        const int nchunks = (n.d.samples_per_buffer + kChunk - 1) / kChunk;
+        const int W = warmup_chunks(n.d.decimate_count);
+        const int min_seg = std::max(4, 6 * W);
+        int nseg = c->opt_segments;
+        if (nseg <= 0) {
+            const int want = (ncu * 12 + level_count[(size_t)n.level] - 1) / level_count[(size_t)n.level];
+            nseg = std::min(want, nchunks / min_seg);
+        }
+        nseg = std::max(1, std::min(nseg, nchunks / std::max(1, std::max(W, 1))));
+        for (int s = 0; s < nseg; ++s) {
+            K1Work w;
+            w.vfo = i;
+            w.c_first_out = (int)((long long)nchunks * s / nseg);
+            w.c_end = (int)((long long)nchunks * (s + 1) / nseg);
+            w.c_begin = s == 0 ? 0 : w.c_first_out - W;
+            if (w.c_begin < 0)
+                return fail(c, SDRX_EUNSUPPORTED, "vfo %d: %d segments do not leave room for %d warm-up chunks", i, nseg, W);
+            if (w.c_end > w.c_first_out)
+                works[(size_t)n.level].push_back(w);
+        }
+    }
+    c->l1.clear();
+    for (int lv = 0; lv < c->n_levels; ++lv) {
+        Launch1 L;
+        L.kind = lv == 0 ? KIND_MIX_ROOT : KIND_MIX_SUB;
+        L.n_work = (int)works[(size_t)lv].size();
+        L.lds_bytes = k1_lds_bytes(level_maxd[(size_t)lv]);
+        L.off_work = plan.take(sizeof(K1Work) * works[(size_t)lv].size());
+        L.alg_bytes = 0;
+        for (const Node &n : c->nodes)
+            if (n.level == lv) // SURVEY.md 8d share of this launch: cf32 consumed (+ cf32 handed to children)
+                L.alg_bytes += 8ll * n.d.samples_per_buffer + (n.leaf ? 0ll : 8ll * n.n_f);
+        c->l1.push_back(L);
+    }
+
+    // ---- block-per-256-outputs launches, grouped by block count
+    std::map<int, std::vector<K2aVfo>> g2a;
+    std::map<int, std::vector<K2Vfo>> g2;
+    std::map<int, std::vector<K3Vfo>> g3;
+    std::map<int, int64_t> b2a, b2, b3;
+    std::map<int, int> lds2a;
+    // descriptors are filled after the arena exists (they hold absolute pointers): remember who goes where
+    struct Pending { int node; int group; int idx; };
+    std::vector<Pending> p2a, p2, p3;
+    for (int i = 0; i < N; ++i) {
+        Node &n = c->nodes[(size_t)i];
+        if (!n.leaf)
+            continue;
+        if (n.d.demod_usb) {
+            if (n.d.late_decimate > 0) {
+                const int g = (n.n_out + 255) / 256;
+                p2a.push_back({i, g, (int)g2a[g].size()});
+                g2a[g].push_back(K2aVfo{});
+                b2a[g] += 0; // intermediate stream only: no algorithmic bytes of its own
+                lds2a[g] = std::max(lds2a[g], (int)sizeof(float2) * (n.d.late_decimate * 255 + (int)n.dec.size()));
+            }
+            const int g = (n.n_out + 255) / 256;
+            p2.push_back({i, g, (int)g2[g].size()});
+            g2[g].push_back(K2Vfo{});
+            b2[g] += n.pay_len; // W_out of SURVEY.md 8d
+        } else {
+            const int g = std::min(64, (n.n_f + 255) / 256);
+            p3.push_back({i, g, (int)g3[g].size()});
+            g3[g].push_back(K3Vfo{});
+            b3[g] += n.pay_len;
+        }
+    }
+    c->lb.clear();
+    std::map<int, size_t> o2a, o2, o3;
+    for (auto &kv : g2a) {
+        o2a[kv.first] = plan.take(sizeof(K2aVfo) * kv.second.size());
+        c->lb.push_back({KIND_LATE_DEC, (int)kv.second.size(), kv.first, o2a[kv.first], lds2a[kv.first], b2a[kv.first]});
+    }
+    for (auto &kv : g2) {
+        o2[kv.first] = plan.take(sizeof(K2Vfo) * kv.second.size());
+        c->lb.push_back({KIND_DEMOD, (int)kv.second.size(), kv.first, o2[kv.first], 0, b2[kv.first]});
+    }
+    for (auto &kv : g3) {
+        o3[kv.first] = plan.take(sizeof(K3Vfo) * kv.second.size());
+        c->lb.push_back({KIND_COMPRESS, (int)kv.second.size(), kv.first, o3[kv.first], 0, b3[kv.first]});
+    }
+    const size_t off_nco_jobs = plan.take(sizeof(NcoInit) * (size_t)N);
+
+    // ---- allocate, zero (= the reference's zero-initialised filter state, dsp.cpp:40-49), fill
+    c->arena_bytes = align_up(plan.size, 256);
+    HIPCHK(c, hipMalloc(&c->arena, c->arena_bytes));
+    HIPCHK(c, hipMemsetAsync(c->arena, 0, c->arena_bytes, c->stream));
+    c->pay_bytes = std::max<size_t>(pay, 64);
+    HIPCHK(c, hipMalloc(&c->d_pay, c->pay_bytes));
+    HIPCHK(c, hipMemsetAsync(c->d_pay, 0, c->pay_bytes, c->stream));
+    HIPCHK(c, hipHostMalloc(&c->h_pay, c->pay_bytes, hipHostMallocDefault));
+    memset(c->h_pay, 0, c->pay_bytes);
+
+    auto P = [&](size_t off) { return c->arena + off; };
+    std::vector<K1Vfo> k1((size_t)N);
+    std::vector<NcoInit> jobs((size_t)N);
+    for (int i = 0; i < N; ++i) {
+        Node &n = c->nodes[(size_t)i];
+        K1Vfo &k = k1[(size_t)i];
+        memset(&k, 0, sizeof k);
+        for (int p = 0; p < 2; ++p) {
+            if (n.d.parent_id >= 0) {
+                const Node &pn = c->nodes[(size_t)n.d.parent_id];
+                k.in[p] = reinterpret_cast<const float2 *>(P(pn.off_stream[p])) + pn.Hx;
+            } else {
+                k.in[p] = nullptr; // raw frame, passed per launch
+            }
+            k.out[p] = reinterpret_cast<float2 *>(P(n.off_stream[p])) + n.Hx;
+            k.hb[p] = reinterpret_cast<float2 *>(P(n.off_hb[p]));
+        }
+        k.cp = reinterpret_cast<const float2 *>(P(n.off_cp));
+        k.rot_re = n.rot_re;
+        k.rot_im = n.rot_im;
+        k.n_in = n.d.samples_per_buffer;
+        k.d = n.d.decimate_count;
+        k.L = n.d.fs;
+        jobs[(size_t)i] = NcoInit{reinterpret_cast<float2 *>(P(n.off_cp)), n.rot_re, n.rot_im, n.d.fs, 0};
+    }
+    for (auto &pe : p2a) {
+        Node &n = c->nodes[(size_t)pe.node];
+        K2aVfo &k = g2a[pe.group][(size_t)pe.idx];
+        for (int p = 0; p < 2; ++p) {
+            k.x[p] = reinterpret_cast<const float2 *>(P(n.off_stream[p]));
+            k.x_next[p] = reinterpret_cast<float2 *>(P(n.off_stream[p ^ 1]));
+            k.z[p] = reinterpret_cast<float2 *>(P(n.off_z[p])) + n.H;
+        }
+        k.taps = reinterpret_cast<const float *>(P(n.off_dec));
+        k.Hx = n.Hx;
+        k.n = n.n_f;
+        k.ndec = (int)n.dec.size();
+        k.L = n.d.late_decimate;
+        k.n_out = n.n_out;
+    }
+    for (auto &pe : p2) {
+        Node &n = c->nodes[(size_t)pe.node];
+        K2Vfo &k = g2[pe.group][(size_t)pe.idx];
+        const bool late = n.d.late_decimate > 0;
+        for (int p = 0; p < 2; ++p) {
+            k.s[p] = reinterpret_cast<const float2 *>(P(late ? n.off_z[p] : n.off_stream[p]));
+            k.s_next[p] = reinterpret_cast<float2 *>(P(late ? n.off_z[p ^ 1] : n.off_stream[p ^ 1]));
+        }
+        k.hilbert = reinterpret_cast<const float *>(P(n.off_hilbert));
+        k.lpf = n.lpf.empty() ? nullptr : reinterpret_cast<const float *>(P(n.off_lpf));
+        k.pay = reinterpret_cast<short *>(c->d_pay + n.pay_off);
+        k.prequant = (c->opt_prequant) ? reinterpret_cast<float *>(P(n.off_preq)) : nullptr;
+        k.gain = n.d.gain;
+        k.H = late ? n.H : n.Hx;
+        k.n = n.n_out;
+        k.nlpf = (int)n.lpf.size();
+    }
+    for (auto &pe : p3) {
+        Node &n = c->nodes[(size_t)pe.node];
+        K3Vfo &k = g3[pe.group][(size_t)pe.idx];
+        for (int p = 0; p < 2; ++p)
+            k.s[p] = reinterpret_cast<const float2 *>(P(n.off_stream[p])) + n.Hx;
+        k.pay = reinterpret_cast<signed char *>(c->d_pay + n.pay_off);
+        k.n = n.n_f;
+        k.cstyle = n.d.cstyle;
+        k.scalecomp = n.d.scalecomp;
+    }
+    auto up = [&](size_t off, const void *src, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(P(off), src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    };
+    HIPCHK(c, up(c->off_k1vfo, k1.data(), sizeof(K1Vfo) * k1.size()));
+    HIPCHK(c, up(off_nco_jobs, jobs.data(), sizeof(NcoInit) * jobs.size()));
+    for (int lv = 0; lv < c->n_levels; ++lv)
+        HIPCHK(c, up(c->l1[(size_t)lv].off_work, works[(size_t)lv].data(), sizeof(K1Work) * works[(size_t)lv].size()));
+    for (auto &kv : g2a)
+        HIPCHK(c, up(o2a[kv.first], kv.second.data(), sizeof(K2aVfo) * kv.second.size()));
+    for (auto &kv : g2)
+        HIPCHK(c, up(o2[kv.first], kv.second.data(), sizeof(K2Vfo) * kv.second.size()));
+    for (auto &kv : g3)
+        HIPCHK(c, up(o3[kv.first], kv.second.data(), sizeof(K3Vfo) * kv.second.size()));
+    for (auto &kv : tap_offsets)
+        HIPCHK(c, up(kv.second, kv.first.data(), kv.first.size() * sizeof(float)));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // host vectors above go out of scope
+
+    // ---- NCO tables: Oscillator::Oscillator for every node, on the device
+    hipLaunchKernelGGL(k_nco_init, dim3((N + 63) / 64), dim3(64), 0, c->stream,
+                       reinterpret_cast<const NcoInit *>(P(off_nco_jobs)), N);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+
+    // ---- publish order: main VFOs in list order, their subs in list order (vfo.cpp:257-263)
+    c->publish_order.clear();
+    std::vector<int> stack;
+    for (int i = N - 1; i >= 0; --i)
+        if (c->nodes[(size_t)i].d.parent_id < 0)
+            stack.push_back(i);
+    while (!stack.empty()) {
+        int i = stack.back();
+        stack.pop_back();
+        const Node &n = c->nodes[(size_t)i];
+        if (n.leaf)
+            c->publish_order.push_back(i);
+        else
+            for (auto it = n.children.rbegin(); it != n.children.rend(); ++it)
+                stack.push_back(*it);
+    }
+    c->finalized = true;
+    return SDRX_OK;
+}
+
+int sdrx_set_stream(sdrx_ctx *c, void *s)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    (void)hipStreamSynchronize(c->stream);
+    c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    return SDRX_OK;
+}
+
+int sdrx_process_device(sdrx_ctx *c, const void *dev_iq, int n_complex)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    if (!c->finalized)
+        return fail(c, SDRX_ESTATE, "sdrx_process before sdrx_finalize");
+    if (n_complex != c->root_frame)
+        return fail(c, SDRX_EINVAL, "frame of %d samples, VFOs were initialised for %d (vfo::init samplesPerBuffer)", n_complex,
+                    c->root_frame);
+    if (!dev_iq)
+        return fail(c, SDRX_EINVAL, "null frame pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    const float2 *raw = reinterpret_cast<const float2 *>(dev_iq);
+    return c->opt_exact ? enqueue_frame<true>(c, raw) : enqueue_frame<false>(c, raw);
+}
+
+int sdrx_sync(sdrx_ctx *c)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    return SDRX_OK;
+}
+
+int sdrx_fetch(sdrx_ctx *c)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    if (!c->finalized)
+        return fail(c, SDRX_ESTATE, "sdrx_fetch before sdrx_finalize");
+    HIPCHK(c, hipMemcpyAsync(c->h_pay, c->d_pay, c->pay_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    c->pending_fetch = false;
+    if (c->cb) {
+        for (int i : c->publish_order) {
+            const Node &n = c->nodes[(size_t)i];
+            // vfo::transmitData (vfo.cpp:426-453): USB leaves always publish; an IQ leaf only with a
+            // topic; ZmqPublisher::publish sends nothing for len 0 (zmqpublisher.cpp:88).
+            if (n.pay_len == 0)
+                continue;
+            if (!n.d.demod_usb && n.d.topic[0] == 0)
+                continue;
+            char topic[5] = {0, 0, 0, 0, 0};
+            for (int k = 0; k < 5 && n.d.topic[k]; ++k)
+                topic[k] = n.d.topic[k];
+            c->cb(c->cb_user, topic, n.rate, c->h_pay + n.pay_off, n.pay_len);
+        }
+    }
+    return SDRX_OK;
+}
+
+int sdrx_process(sdrx_ctx *c, const float *iq, int n_complex)
+{
+    if (!c || !iq)
+        return SDRX_EINVAL;
+    if (!c->finalized)
+        return fail(c, SDRX_ESTATE, "sdrx_process before sdrx_finalize");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_raw(c, (size_t)c->root_frame);
+    if (rc)
+        return rc;
+    if (n_complex != c->root_frame)
+        return fail(c, SDRX_EINVAL, "frame of %d samples, VFOs were initialised for %d (vfo::init samplesPerBuffer)", n_complex,
+                    c->root_frame);
+    HIPCHK(c, hipMemcpyAsync(c->d_raw, iq, (size_t)n_complex * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    rc = sdrx_process_device(c, c->d_raw, n_complex);
+    if (rc)
+        return rc;
+    return sdrx_fetch(c);
+}
+
+int sdrx_process_u8(sdrx_ctx *c, const uint8_t *, int, int)
+{
+    return fail(c, SDRX_EUNSUPPORTED, "sdrx_process_u8: device-side byte ingest is not built yet");
+}
+
+int sdrx_get_output(sdrx_ctx *c, int id, const void **buf, uint32_t *len, uint32_t *rate)
+{
+    if (!c || id < 0 || id >= (int)c->nodes.size())
+        return fail(c, SDRX_EINVAL, "bad vfo id %d", id);
+    if (!c->finalized)
+        return fail(c, SDRX_ESTATE, "sdrx_get_output before sdrx_finalize");
+    const Node &n = c->nodes[(size_t)id];
+    if (!n.leaf)
+        return fail(c, SDRX_EINVAL, "vfo %d has children and publishes nothing (vfo.cpp:253-266)", id);
+    if (c->pending_fetch) {
+        int rc = sdrx_fetch(c);
+        if (rc)
+            return rc;
+    }
+    if (buf)
+        *buf = c->h_pay + n.pay_off;
+    if (len)
+        *len = n.pay_len;
+    if (rate)
+        *rate = n.rate;
+    return SDRX_OK;
+}
+
+int sdrx_get_stream(sdrx_ctx *c, int id, float *out, int max_complex, int *n_ret)
+{
+    if (!c || id < 0 || id >= (int)c->nodes.size())
+        return fail(c, SDRX_EINVAL, "bad vfo id %d", id);
+    if (!c->finalized || c->frame_no == 0)
+        return fail(c, SDRX_ESTATE, "sdrx_get_stream: no frame processed yet");
+    const Node &n = c->nodes[(size_t)id];
+    const int par = (int)((c->frame_no - 1) & 1ull);
+    const int cnt = std::min(max_complex, n.n_f);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out && cnt > 0)
+        HIPCHK(c, hipMemcpy(out, c->arena + n.off_stream[par] + sizeof(float2) * (size_t)n.Hx, sizeof(float2) * (size_t)cnt,
+                            hipMemcpyDeviceToHost));
+    if (n_ret)
+        *n_ret = n.n_f;
+    return SDRX_OK;
+}
+
+int sdrx_get_prequant(sdrx_ctx *c, int id, float *out, int max, int *n_ret)
+{
+    if (!c || id < 0 || id >= (int)c->nodes.size())
+        return fail(c, SDRX_EINVAL, "bad vfo id %d", id);
+    const Node &n = c->nodes[(size_t)id];
+    if (!c->finalized || !c->opt_prequant || !n.leaf || !n.d.demod_usb)
+        return fail(c, SDRX_ESTATE, "sdrx_get_prequant: set option keep_prequant=1 before finalize; USB leaves only");
+    const int cnt = std::min(max, n.n_out);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out && cnt > 0)
+        HIPCHK(c, hipMemcpy(out, c->arena + n.off_preq, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost));
+    if (n_ret)
+        *n_ret = n.n_out;
+    return SDRX_OK;
+}
+
+int sdrx_get_taps(sdrx_ctx *c, int id, int which, float *out, int max, int *n_ret)
+{
+    if (!c || id < 0 || id >= (int)c->nodes.size())
+        return fail(c, SDRX_EINVAL, "bad vfo id %d", id);
+    if (!c->finalized)
+        return fail(c, SDRX_ESTATE, "sdrx_get_taps before sdrx_finalize");
+    const Node &n = c->nodes[(size_t)id];
+    const std::vector<float> *t = which == 0 ? &n.lpf : which == 1 ? &n.dec : which == 2 ? &n.hilbert : nullptr;
+    if (!t)
+        return fail(c, SDRX_EINVAL, "which must be 0, 1 or 2");
+    // read back what the kernels actually use (device copy), not the host vector
+    const size_t off = which == 0 ? n.off_lpf : which == 1 ? n.off_dec : n.off_hilbert;
+    const int cnt = std::min(max, (int)t->size());
+    if (out && cnt > 0)
+        HIPCHK(c, hipMemcpy(out, c->arena + off, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost));
+    if (n_ret)
+        *n_ret = (int)t->size();
+    return SDRX_OK;
+}
+
+int sdrx_get_nco(sdrx_ctx *c, int id, long first, long count, float *out)
+{
+    if (!c || id < 0 || id >= (int)c->nodes.size())
+        return fail(c, SDRX_EINVAL, "bad vfo id %d", id);
+    if (!c->finalized)
+        return fail(c, SDRX_ESTATE, "sdrx_get_nco before sdrx_finalize");
+    const Node &n = c->nodes[(size_t)id];
+    if (first < 0 || count < 0 || first + count > n.d.fs)
+        return fail(c, SDRX_EINVAL, "table range [%ld,%ld) outside 0..%d", first, first + count, n.d.fs);
+    if (count == 0)
+        return SDRX_OK;
+    float2 *tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, sizeof(float2) * (size_t)count));
+    hipLaunchKernelGGL(k_nco_dump, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const float2 *>(c->arena + n.off_cp), n.rot_re, n.rot_im, first, count, tmp);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy(out, tmp, sizeof(float2) * (size_t)count, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess)
+        return fail(c, SDRX_EHIP, "sdrx_get_nco: %s", hipGetErrorString(e));
+    return SDRX_OK;
+}
+
+int sdrx_get_stats(sdrx_ctx *c, sdrx_stats *s)
+{
+    if (!c || !s)
+        return SDRX_EINVAL;
+    memset(s, 0, sizeof *s);
+    s->n_vfos = (int)c->nodes.size();
+    for (const Node &n : c->nodes)
+        s->n_leaves += n.children.empty();
+    s->n_levels = c->n_levels;
+    s->exact = c->opt_exact;
+    s->algorithmic_bytes_per_frame = c->alg_bytes;
+    s->vfo_samples_per_frame = c->vfo_samples;
+    s->device_bytes = (int64_t)(c->arena_bytes + c->pay_bytes + c->raw_cap * 10);
+    s->frames = (int64_t)c->frame_no;
+    return SDRX_OK;
+}
+
+int sdrx_enable_kernel_timing(sdrx_ctx *c, int enable)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    (void)hipStreamSynchronize(c->stream);
+    drain_events(c);
+    c->timing = enable != 0;
+    for (int k = 0; k < SDRX_NKERNELS; ++k) {
+        c->t_ms[k] = 0;
+        c->t_n[k] = 0;
+        c->t_bytes[k] = 0;
+    }
+    return SDRX_OK;
+}
+
+int sdrx_get_kernel_times(sdrx_ctx *c, double ms[SDRX_NKERNELS], int64_t launches[SDRX_NKERNELS],
+                          int64_t alg_bytes[SDRX_NKERNELS])
+{
+    if (!c)
+        return SDRX_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    for (int k = 0; k < SDRX_NKERNELS; ++k) {
+        if (ms)
+            ms[k] = c->t_ms[k];
+        if (launches)
+            launches[k] = c->t_n[k];
+        if (alg_bytes)
+            alg_bytes[k] = c->t_bytes[k];
+    }
+    return SDRX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,76 @@
+// sdrx_dev.h -- device-visible descriptors shared by the kernels and the host orchestration.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sdrx {
+
+constexpr int kRun = 16;            // input samples per lane per chunk (NCO checkpoint spacing)
+constexpr int kChunk = 64 * kRun;   // 1024 input samples per wave-iteration
+constexpr int kCarry = 16;          // per-stage history window kept in LDS between chunks
+constexpr int kHbHist = 10;         // half-band history carried between frames (x[-1..-10])
+constexpr int kMaxStages = 8;       // vfo.h:63
+constexpr int kHilbert = 125;       // vfo.cpp:137
+constexpr int kHilbertNz = 62;      // non-zero Hilbert taps (odd indices 1..123)
+constexpr int kDelay = 62;          // vfo.cpp:136
+constexpr int kMaxFir = 256;        // longest low-pass the demod kernels stage in LDS
+
+// ---- mix + half-band cascade (one per VFO) ---------------------------------------------------
+struct K1Vfo {
+    const float2 *in[2];   // input stream (sample 0 of the frame) per frame parity; null = raw frame arg
+    float2 *out[2];        // decimate[d] of this frame, per frame parity
+    const float2 *cp;      // NCO checkpoints: cp[j] = table[16 j - 1], cp[0] = (1,0), cp[L/16] = table[L-1]
+    float2 *hb[2];         // half-band history per frame parity: [d][10], entry k-1 = x[-k]
+    float rot_re, rot_im;  // NCO rotation (float cos, float sin of the double angle)
+    int n_in;              // complex samples per frame
+    int d;                 // half-band stages
+    int L;                 // NCO table length = (int)fs
+    int pad_;
+};
+
+// One wave's job: chunks [c_begin, c_end) of one VFO-frame; chunks before c_first_out only warm
+// the filter state up (mid-frame segment start) and emit nothing.
+struct K1Work {
+    int vfo;
+    int c_begin, c_first_out, c_end;
+};
+
+// ---- late decimation by L (vfo::usb_decimdemod, vfo.cpp:334-387) ------------------------------
+struct K2aVfo {
+    const float2 *x[2];     // [hist Hx | data n] per parity
+    float2 *x_next[2];      // the other parity's buffer (history for the next frame)
+    float2 *z[2];           // output stream data base (after ITS history) per parity
+    const float *taps;      // Nd taps
+    int Hx, n, ndec, L;
+    int n_out;              // n / L
+    int pad_;
+};
+
+// ---- USB demod + audio low-pass + int16 (vfo::usb_demod, vfo.cpp:300-332) ---------------------
+struct K2Vfo {
+    const float2 *s[2];     // [hist H | data n] per parity
+    float2 *s_next[2];
+    const float *hilbert;   // 125 taps
+    const float *lpf;       // nlpf taps or null
+    short *pay;             // n int16
+    float *prequant;        // optional n floats
+    float gain;
+    int H, n, nlpf;
+};
+
+// ---- compress() for childless non-USB VFOs (vfo.cpp:389-424) ----------------------------------
+struct K3Vfo {
+    const float2 *s[2];
+    signed char *pay;
+    int n, cstyle, scalecomp;
+    int pad_;
+};
+
+struct NcoInit {
+    float2 *cp;
+    float rot_re, rot_im;
+    int L;
+    int pad_;
+};
+
+} // namespace sdrx

@@ -1,0 +1,282 @@
+"""Host-side mirror of the reference interface for the VFO chain, over the C ABI.
+
+Two layers:
+
+* :class:`Receiver` -- thin object wrapper around ``sdrx_*`` (one context = one VFO tree).
+* :class:`vfo` and :class:`sdrj` -- the reference's own class and method names (vfo.h:16-49,
+  sdrj.h:29-48) so that host code and parity tests read like reference-side code:
+  ``v = vfo(); v.setFs(...); v.setMixerFreq(...); v.init(n, True); main.setVFOs([...]);
+  radio = sdrj(); radio.setVFOs([main]); radio.demodData(data, len)``.
+
+Everything here is plumbing; the arithmetic runs in the HIP kernels of libsdrx.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .topology import Topology, VfoDesc
+
+
+class SdrxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"sdrx error {code}: {msg}")
+        self.code = code
+
+
+class Receiver:
+    """One libsdrx context: a VFO tree on one GPU."""
+
+    def __init__(self, device: int = 0, exact: bool = True, keep_prequant: bool = False, segments: int = 0):
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        rc = self.L.sdrx_create(C.byref(h), int(device))
+        if rc != 0:
+            raise SdrxError(rc, self.L.sdrx_last_error(None).decode())
+        self.h = h
+        self.descs: list[VfoDesc] = []
+        self.published: list[tuple[bytes, int, bytes]] = []
+        self._cb = _lib.PUBLISH_FN(self._on_publish)
+        self._chk(self.L.sdrx_set_publish_callback(self.h, self._cb, None))
+        self._chk(self.L.sdrx_set_option(self.h, b"exact", int(bool(exact))))
+        self._chk(self.L.sdrx_set_option(self.h, b"keep_prequant", int(bool(keep_prequant))))
+        self._chk(self.L.sdrx_set_option(self.h, b"segments", int(segments)))
+        self.finalized = False
+
+    # -- plumbing -----------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            raise SdrxError(rc, self.L.sdrx_last_error(self.h).decode())
+
+    def _on_publish(self, user, topic, rate, buf, length):
+        self.published.append((C.string_at(topic, 5), int(rate), C.string_at(buf, length)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sdrx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration --------------------------------------------------------------
+    def add_vfo(self, d: VfoDesc) -> int:
+        c = _lib.VfoDescC(fs=d.fs, decimate_count=d.decimate_count, mixer_freq_hz=float(d.mixer_freq),
+                          demod_usb=int(d.demod_usb), late_decimate=d.late_decimate, filter_bw_hz=int(d.filter_bw),
+                          gain=float(d.gain), cstyle=d.cstyle, scalecomp=d.scalecomp, parent_id=d.parent,
+                          samples_per_buffer=d.samples_per_buffer, topic=d.topic.encode()[:7])
+        out = C.c_int(-1)
+        self._chk(self.L.sdrx_add_vfo(self.h, C.byref(c), C.byref(out)))
+        self.descs.append(d)
+        return out.value
+
+    def finalize(self):
+        self._chk(self.L.sdrx_finalize(self.h))
+        self.finalized = True
+
+    @classmethod
+    def from_topology(cls, topo: Topology, **kw) -> "Receiver":
+        r = cls(**kw)
+        for d in topo.vfos:
+            r.add_vfo(d)
+        r.finalize()
+        return r
+
+    # -- per frame ----------------------------------------------------------------------
+    def process(self, iq) -> None:
+        """One frame of interleaved float32 I/Q on the host (sdrj::demodData's argument)."""
+        iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
+        self.published.clear()
+        self._chk(self.L.sdrx_process(self.h, iq.ctypes.data, iq.size // 2))
+
+    def process_device(self, dev_ptr: int, n_complex: int) -> None:
+        self._chk(self.L.sdrx_process_device(self.h, C.c_void_p(dev_ptr), int(n_complex)))
+
+    def fetch(self) -> None:
+        self.published.clear()
+        self._chk(self.L.sdrx_fetch(self.h))
+
+    def sync(self) -> None:
+        self._chk(self.L.sdrx_sync(self.h))
+
+    def set_stream(self, hip_stream: int | None) -> None:
+        self._chk(self.L.sdrx_set_stream(self.h, C.c_void_p(hip_stream or 0)))
+
+    # -- results ------------------------------------------------------------------------
+    def output(self, vid: int) -> np.ndarray:
+        buf, ln, rate = C.c_void_p(), C.c_uint32(), C.c_uint32()
+        self._chk(self.L.sdrx_get_output(self.h, vid, C.byref(buf), C.byref(ln), C.byref(rate)))
+        raw = C.string_at(buf.value, ln.value)
+        return np.frombuffer(raw, dtype=np.int16 if self.descs[vid].demod_usb else np.int8).copy()
+
+    def output_rate(self, vid: int) -> int:
+        rate = C.c_uint32()
+        self._chk(self.L.sdrx_get_output(self.h, vid, None, None, C.byref(rate)))
+        return rate.value
+
+    def stream(self, vid: int) -> np.ndarray:
+        n = C.c_int()
+        self._chk(self.L.sdrx_get_stream(self.h, vid, None, 0, C.byref(n)))
+        out = np.zeros(2 * max(n.value, 1), np.float32)
+        self._chk(self.L.sdrx_get_stream(self.h, vid, out.ctypes.data, n.value, C.byref(n)))
+        return out[: 2 * n.value].view(np.complex64).copy()
+
+    def prequant(self, vid: int) -> np.ndarray:
+        n = C.c_int()
+        self._chk(self.L.sdrx_get_prequant(self.h, vid, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.float32)
+        self._chk(self.L.sdrx_get_prequant(self.h, vid, out.ctypes.data, n.value, C.byref(n)))
+        return out[: n.value].copy()
+
+    def taps(self, vid: int, which: str) -> np.ndarray:
+        w = {"fir_usb": 0, "fir_dec": 1, "hilbert": 2}[which]
+        n = C.c_int()
+        self._chk(self.L.sdrx_get_taps(self.h, vid, w, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.float32)
+        self._chk(self.L.sdrx_get_taps(self.h, vid, w, out.ctypes.data, n.value, C.byref(n)))
+        return out[: n.value].copy()
+
+    def nco(self, vid: int, first: int, count: int) -> np.ndarray:
+        out = np.zeros(2 * max(count, 1), np.float32)
+        self._chk(self.L.sdrx_get_nco(self.h, vid, first, count, out.ctypes.data))
+        return out[: 2 * count].view(np.complex64).copy()
+
+    # -- measurement -----------------------------------------------------------------------
+    def stats(self) -> dict:
+        s = _lib.StatsC()
+        self._chk(self.L.sdrx_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def enable_kernel_timing(self, on: bool) -> None:
+        self._chk(self.L.sdrx_enable_kernel_timing(self.h, int(on)))
+
+    def kernel_times(self) -> dict:
+        ms = (C.c_double * _lib.NKERNELS)()
+        n = (C.c_int64 * _lib.NKERNELS)()
+        b = (C.c_int64 * _lib.NKERNELS)()
+        self._chk(self.L.sdrx_get_kernel_times(self.h, ms, n, b))
+        return {self.L.sdrx_kernel_name(k).decode(): {"ms": ms[k], "launches": n[k], "alg_bytes": b[k]}
+                for k in range(_lib.NKERNELS) if n[k]}
+
+
+# =============================================================================================
+# The reference's own names
+# =============================================================================================
+class vfo:  # noqa: N801  (the reference's class name, vfo.h:11)
+    """Mirror of ``class vfo`` (vfo.h:11-116): same setters, ``init`` and ``setVFOs``.  Nodes
+    only collect parameters; the tree is instantiated on the GPU by the :class:`sdrj` that
+    owns the main VFOs, at its first ``demodData`` (or an explicit ``start``)."""
+
+    def __init__(self):
+        self.desc = VfoDesc(gain=float(np.float32(0.01)), demod_usb=True, scalecomp=1)  # vfo.cpp:6-31
+        self.children: list[vfo] = []
+        self._radio: "sdrj | None" = None
+        self._id = -1
+        self._init = False
+
+    def setFs(self, samplerate): self.desc.fs = int(samplerate)
+    def setDecimationCount(self, count): self.desc.decimate_count = int(count)
+    def setMixerFreq(self, freq): self.desc.mixer_freq = float(freq)
+    def getMixerFreq(self): return self.desc.mixer_freq
+    def getOutRate(self): return self.desc.out_rate_stage
+    def setFilterBandwidth(self, bw): self.desc.filter_bw = int(bw)
+    def setGain(self, g): self.desc.gain = float(np.float32(g))
+    def setDemodUSB(self, usb): self.desc.demod_usb = bool(usb)
+    def getDemodUSB(self): return self.desc.demod_usb
+    def setCompressonStyle(self, st): self.desc.cstyle = int(st)  # sic
+    def setScaleComp(self, scale): self.desc.scalecomp = int(scale)
+    def setZmqTopic(self, topic): self.desc.topic = str(topic)
+    def setZmqAddress(self, address): self.zmqAddress = str(address)  # socket stays host-side
+
+    def init(self, samplesPerBuffer, bind=True, lateDecimate=0):
+        self.desc.samples_per_buffer = int(samplesPerBuffer)
+        self.desc.late_decimate = int(lateDecimate)
+        self._init = True
+
+    def setVFOs(self, pVFOs):
+        self.children = list(pVFOs)
+
+    # observation, available once the owning sdrj has started
+    def _r(self) -> Receiver:
+        if self._radio is None or self._radio.rx is None:
+            raise RuntimeError("vfo is not attached to a started sdrj")
+        return self._radio.rx
+
+    @property
+    def transmit_usb(self): return self._r().output(self._id)
+    @property
+    def transmit_iq(self): return self._r().output(self._id)
+    @property
+    def decimate_final(self): return self._r().stream(self._id)
+    @property
+    def outputRate(self): return self._r().output_rate(self._id)
+
+
+class sdrj:  # noqa: N801  (the reference's class name, sdrj.h)
+    """Mirror of the hot-path part of ``class sdrj``: ``setVFOs`` (sdrj.h) and
+    ``demodData(const float*, int)`` (sdrj.cpp:266-305).  ``setDCCorrection`` keeps the DC-bias
+    IIR on the host side for float input, exactly where the reference has it."""
+
+    def __init__(self, device: int = 0, exact: bool = True, keep_prequant: bool = False):
+        self.mains: list[vfo] = []
+        self.rx: Receiver | None = None
+        self.correctDC = False
+        self._avept = np.zeros(2, np.float32)
+        self._kw = dict(device=device, exact=exact, keep_prequant=keep_prequant)
+
+    def setVFOs(self, vfos): self.mains = list(vfos)
+    def setDCCorrection(self, dc): self.correctDC = bool(dc)
+
+    def start(self):
+        self.rx = Receiver(**self._kw)
+
+        def add(node: vfo, parent: int):
+            if not node._init:
+                raise RuntimeError("vfo::init was not called")
+            node.desc.parent = parent
+            node._id = self.rx.add_vfo(node.desc)
+            node._radio = self
+            for ch in node.children:
+                add(ch, node._id)
+
+        # ids must be assigned parents-first; children of main i come before main i+1's, which
+        # is also the reference's publish order (sdrj.cpp:288-294, vfo.cpp:257-263)
+        for m in self.mains:
+            add(m, -1)
+        self.rx.finalize()
+
+    def demodData(self, data, length=None):
+        if self.rx is None:
+            self.start()
+        data = np.ascontiguousarray(data, dtype=np.float32).reshape(-1)
+        if length is not None:
+            data = data[: int(length)]
+        if self.correctDC:
+            data = data.copy()
+            _dc_correct(data, self._avept)
+        self.rx.process(data)
+
+    @property
+    def published(self):
+        return self.rx.published if self.rx else []
+
+
+def _dc_correct(iq: np.ndarray, state: np.ndarray) -> None:
+    """sdrj.cpp:277-283 on the host: avept = avept*(1-1e-6) + 1e-6*curr; curr -= avept, in fp32.
+    A first-order recursion; evaluated blockwise in closed form is not bit-exact, so this is the
+    plain sequential loop the reference runs (the device-side version lives in the library)."""
+    keep = np.float32(1.0) - np.float32(0.000001)
+    k = np.float32(0.000001)
+    ar, ai = np.float32(state[0]), np.float32(state[1])
+    re, im = iq[0::2], iq[1::2]
+    for i in range(re.size):
+        ar = np.float32(np.float32(ar * keep) + np.float32(k * re[i]))
+        ai = np.float32(np.float32(ai * keep) + np.float32(k * im[i]))
+        re[i] -= ar
+        im[i] -= ai
+    state[0], state[1] = ar, ai
