@@ -86,155 +86,171 @@ __device__ __forceinline__ float hb_dot(float w0, float w2, float w4, float w5, 
     }
 }
 
-// LDS layout of k_mix_decimate (bytes).  `raw`: the input chunk as 512 float4 units (2 samples
-// each), one pad unit after every 8 so that the per-lane 128-byte runs are bank-conflict free
-// for ds_read_b128.  Stage arrays A_s: [16 carry | (1024 >> s) data] float2 in a linear index
-// space p; A_0 alone is stored through pad0() because it is WRITTEN as 16-sample lane runs.
-constexpr int kRawUnits = 512 + 512 / 8;                 // 576 float4
-constexpr int kRawBytes = kRawUnits * 16;                // 9216
-__host__ __device__ constexpr int pad0(int p) { return p + 2 * (p >> 4); }
-constexpr int kA0Elems = kCarry + kChunk + 2 * ((kCarry + kChunk) >> 4) + 2; // 1172
-__host__ __device__ constexpr int stage_elems(int s) { return s == 0 ? kA0Elems : kCarry + (kChunk >> s); }
-__host__ __device__ constexpr int stage_offset(int s)
+// ------------------------------------------------------------------------------------ streams
+// TILE LAYOUT.  Every cf32 stream that feeds k_mix_decimate is stored in tiles of 1024 samples:
+// tile c is 512 float4 units [i2 = 0..7][lane = 0..63]; unit (i2, lane) holds samples
+// c*1024 + lane*16 + 2*i2 and +1.  A wave then loads its chunk as 8 fully coalesced 1 KiB
+// instructions and every lane ends up with 16 CONSECUTIVE samples in registers -- the shape both
+// the NCO replay and the register-resident half-band stages want -- with no LDS transpose.
+__device__ __forceinline__ size_t tile_unit(int chunk, int i2, int lane) { return (size_t)chunk * 512 + i2 * 64 + lane; }
+// float2 index of natural sample g inside a tile-layout stream
+__device__ __forceinline__ size_t tile_pos(int g)
+{
+    const int c = g >> 10, r = g & 1023, ln = r >> 4, i = r & 15;
+    return (size_t)c * 1024 + (i >> 1) * 128 + ln * 2 + (i & 1);
+}
+
+// natural cf32 frame -> tile layout (host-fed / broadcast raw frames enter the pipeline here)
+__global__ __launch_bounds__(256) void k_ingest_f32(const float4 *__restrict__ nat, float4 *__restrict__ tiled, int n_pairs)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pairs)
+        return;
+    const int c = p >> 9, r = p & 511;
+    tiled[tile_unit(c, r & 7, r >> 3)] = nat[p];
+}
+
+// ------------------------------------------------------------------------------------ k_mix_decimate
+// Whole-wave DPP shift by one lane (GFX9 `wave_shr:1`): lane l receives src of lane l-1,
+// lane 0 keeps `old`.  Lane semantics verified on gfx950 by tools/dpp_probe.hip.
+__device__ __forceinline__ float shr1(float old, float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float2 shr1(float2 old, float2 src) { return make_float2(shr1(old.x, src.x), shr1(old.y, src.y)); }
+
+// LDS of k_mix_decimate (per wave): two 8-entry carry rows for the register stages, then the
+// linear stage arrays A_s = [16 carry | 1024 >> s data] for the stages s >= 2 that run in LDS,
+// and (only when a d == 0 VFO must emit natural order) a padded transpose tile.
+constexpr int kRegStages = 2;                       // stages 0 and 1 live in registers
+constexpr int kCarryBytes = 2 * 8 * 8;              // car0[8], car1[8] float2
+__host__ __device__ constexpr int stage_elems(int s) { return kCarry + (kChunk >> s); }
+__host__ __device__ constexpr int stage_offset(int s) // float2 index of A_s, s >= kRegStages
 {
     int o = 0;
-    for (int t = 0; t < s; ++t)
+    for (int t = kRegStages; t < s; ++t)
         o += stage_elems(t);
     return o;
 }
-__host__ __device__ constexpr int k1_lds_bytes(int d)
+__host__ __device__ constexpr int pad0(int p) { return p + 2 * (p >> 4); }
+constexpr int kTransposeElems = kChunk + 2 * (kChunk >> 4); // 1152 float2
+__host__ __device__ constexpr int k1_lds_bytes(int d, bool need_transpose)
 {
-    return kRawBytes + 8 * stage_offset(d < 1 ? 1 : d);
+    int stages = 8 * stage_offset(d < kRegStages ? kRegStages : d);
+    int tr = need_transpose ? 8 * kTransposeElems : 0;
+    return kCarryBytes + (stages > tr ? stages : tr);
 }
 
-template <int S>
-__device__ __forceinline__ int amap(int p)
-{
-    return S == 0 ? pad0(p) : p;
-}
-
-// One half-band stage of one chunk, fully in LDS: A (stage S input, linear space with carry)
-// -> B (stage S+1 input) or global `out` when S is the last stage.
-template <bool EXACT, int S>
-__device__ __forceinline__ void hb_stage(float2 *__restrict__ A, float2 *__restrict__ B, float2 *__restrict__ gout,
-                                         bool last, bool emit, int cnt, int lane, bool save, float2 *__restrict__ hbsave)
+// One half-band stage of one chunk in LDS (stages >= 2): A = [16 carry | cnt data] -> B data, or
+// the output stream when this is the last stage.
+template <bool EXACT>
+__device__ __forceinline__ void hb_stage_lds(float2 *__restrict__ A, float2 *__restrict__ B, float2 *__restrict__ gout,
+                                             int gbase, bool tiled, bool last, bool emit, int cnt, int lane, bool save,
+                                             float2 *__restrict__ hbsave)
 {
     __syncthreads(); // stage input (written by the previous phase) is visible
     const int nout = cnt >> 1;
     for (int j = lane; j < nout; j += 64) {
-        const int p = kCarry + 2 * j - 10; // window p .. p+10, newest = input sample 2j of this chunk
-        float2 w0 = A[amap<S>(p)], w2 = A[amap<S>(p + 2)], w4 = A[amap<S>(p + 4)], w5 = A[amap<S>(p + 5)],
-               w6 = A[amap<S>(p + 6)], w8 = A[amap<S>(p + 8)], w10 = A[amap<S>(p + 10)];
+        const float2 *w = A + kCarry + 2 * j - 10; // w[0..10], newest = input sample 2j of this chunk
+        float2 w0 = w[0], w2 = w[2], w4 = w[4], w5 = w[5], w6 = w[6], w8 = w[8], w10 = w[10];
         float2 y;
         y.x = hb_dot<EXACT>(w0.x, w2.x, w4.x, w5.x, w6.x, w8.x, w10.x);
         y.y = hb_dot<EXACT>(w0.y, w2.y, w4.y, w5.y, w6.y, w8.y, w10.y);
         if (!last)
-            B[amap<S + 1>(kCarry + j)] = y;
+            B[kCarry + j] = y;
         else if (emit)
-            gout[j] = y;
+            gout[tiled ? tile_pos(gbase + j) : (size_t)(gbase + j)] = y;
     }
     __syncthreads(); // all window reads done before the carry is overwritten
-    // FIRQueueBackToFront (dsp.cpp:163-173) at the end of the FRAME: the 10 samples before the
-    // LAST one become the next frame's history: x[-k] := x[size-1-k].
+    // FIRQueueBackToFront (dsp.cpp:163-173) at the end of the FRAME: x[-k] := x[size-1-k]
     if (save && lane < kHbHist)
-        hbsave[lane] = A[amap<S>(kCarry + cnt - 2 - lane)];
-    // Between chunks of one frame the stream is simply continuous: keep the last 16 samples.
+        hbsave[lane] = A[kCarry + cnt - 2 - lane];
     float2 t;
     if (lane < kCarry)
-        t = A[amap<S>(cnt + lane)];
+        t = A[cnt + lane]; // the last 16 of [carry | data]
     __syncthreads();
     if (lane < kCarry)
-        A[amap<S>(lane)] = t;
+        A[lane] = t;
 }
 
-template <bool EXACT, int S>
-struct StageChain {
-    static __device__ __forceinline__ void run(float2 *lds, int d, float2 *gout, bool emit, int valid, int lane,
-                                               bool save, float2 *hbsave)
-    {
-        if (S < d) {
-            hb_stage<EXACT, S>(lds + stage_offset(S), lds + stage_offset(S + 1), gout, S + 1 == d, emit, valid >> S,
-                               lane, save, hbsave + S * kHbHist);
-            StageChain<EXACT, S + 1>::run(lds, d, gout, emit, valid, lane, save, hbsave);
-        }
+// 8 outputs of a register-resident stage from 16 own inputs + 8 halo values.
+// ext[k] holds input sample k-10 of this lane's run (k = 0..9 halo, only the needed ones set).
+template <bool EXACT, int NOUT>
+__device__ __forceinline__ void hb_regs(const float2 *ext, float2 *y)
+{
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+        const float2 *w = ext + 2 * j; // w[t] = input sample 2j - 10 + t
+        y[j].x = hb_dot<EXACT>(w[0].x, w[2].x, w[4].x, w[5].x, w[6].x, w[8].x, w[10].x);
+        y[j].y = hb_dot<EXACT>(w[0].y, w[2].y, w[4].y, w[5].y, w[6].y, w[8].y, w[10].y);
     }
-};
-template <bool EXACT>
-struct StageChain<EXACT, kMaxStages> {
-    static __device__ __forceinline__ void run(float2 *, int, float2 *, bool, int, int, bool, float2 *) {}
-};
+}
+
+// halo slot q (0..7) <-> distance k back from the lane's first sample: -10,-8,-6,-5,-4,-3,-2,-1
+__device__ __forceinline__ constexpr int halo_k(int q) { return q == 0 ? 10 : q == 1 ? 8 : q == 2 ? 6 : 8 - q; }
 
 // Fused NCO + mixer + half-band cascade.  One wave per workgroup, one workgroup per K1Work.
-template <bool EXACT>
+// LEVEL only gives the root launch and the sub launches distinct kernel names in profiles.
+template <bool EXACT, int LEVEL>
 __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ vfos, const K1Work *__restrict__ work,
-                                                     const float2 *__restrict__ raw_frame,
                                                      unsigned long long frame_no)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4 *raw = reinterpret_cast<float4 *>(smem);
-    float2 *lds = reinterpret_cast<float2 *>(smem + kRawBytes);
+    float2 *car0 = reinterpret_cast<float2 *>(smem);      // [8]
+    float2 *car1 = car0 + 8;                               // [8]
+    float2 *lds = reinterpret_cast<float2 *>(smem + kCarryBytes);
 
     const K1Work W = work[blockIdx.x];
     const int lane = threadIdx.x;
     const int par = (int)(frame_no & 1ull);
-    // Scalar (wave-uniform) loads of the descriptor; the parity-indexed pointers are read
-    // straight from memory so the struct never becomes a runtime-indexed private array.
     const K1Vfo *Dp = vfos + W.vfo;
     struct {
         const float2 *cp;
         float rot_re, rot_im;
-        int n_in, d, L;
-    } D = {Dp->cp, Dp->rot_re, Dp->rot_im, Dp->n_in, Dp->d, Dp->L};
-    const float2 *in = Dp->in[par] ? Dp->in[par] : raw_frame;
+        int n_in, d, L, out_tiled;
+    } D = {Dp->cp, Dp->rot_re, Dp->rot_im, Dp->n_in, Dp->d, Dp->L, Dp->out_tiled};
+    const float4 *in = reinterpret_cast<const float4 *>(Dp->in[par]);
     float2 *out = Dp->out[par];
-    float2 *hb_load = Dp->hb[par];
+    const float2 *hb_load = Dp->hb[par];
     float2 *hb_save = Dp->hb[par ^ 1];
     const int nchunks = (D.n_in + kChunk - 1) / kChunk;
+    const bool from_state = W.c_begin == 0;
 
-    // Filter state at the start of this segment.  Segment 0 continues from the previous frame's
-    // saved history (zero at start-up, dsp.cpp:40-49); a later segment starts from zeros and
-    // runs warm-up chunks until every stage's window holds real samples again.
-    const int nst = D.d < 1 ? 1 : D.d;
-    for (int s = 0; s < nst; ++s) {
-        if (lane < kCarry) {
-            float2 v = make_float2(0.f, 0.f);
-            const int k = kCarry - lane; // position `lane` of the carry is x[-k]
-            if (W.c_begin == 0 && k <= kHbHist && s < D.d)
-                v = hb_load[s * kHbHist + (k - 1)];
-            const int p = lane;
-            lds[stage_offset(s) + (s == 0 ? pad0(p) : p)] = v;
-        }
+    // Filter state at the start of this segment: segment 0 continues from the previous frame's
+    // history (zero at start-up, dsp.cpp:40-49); a later segment starts from zeros and runs
+    // warm-up chunks until every stage's window holds real samples again.
+    if (lane < 8) {
+        const int k = halo_k(lane);
+        car0[lane] = (from_state && D.d > 0) ? hb_load[0 * kHbHist + k - 1] : make_float2(0.f, 0.f);
+        car1[lane] = (from_state && D.d > 1) ? hb_load[1 * kHbHist + k - 1] : make_float2(0.f, 0.f);
     }
+    for (int s = kRegStages; s < D.d; ++s)
+        if (lane < kCarry) {
+            const int k = kCarry - lane; // carry position `lane` is x[-k]
+            lds[stage_offset(s) + lane] = (from_state && k <= kHbHist) ? hb_load[s * kHbHist + k - 1] : make_float2(0.f, 0.f);
+        }
     const int phase_frame = (int)((frame_no * (unsigned long long)D.n_in) % (unsigned long long)D.L);
 
     for (int c = W.c_begin; c < W.c_end; ++c) {
         const int base = c * kChunk;
         const int valid = min(kChunk, D.n_in - base);
         const bool emit = c >= W.c_first_out;
-        const bool last_chunk = c == nchunks - 1;
+        const bool save = c == nchunks - 1 && W.c_end == nchunks;
+        const int lv = (valid >> 4) - 1; // last lane holding real samples
+        const bool active = lane <= lv;
 
-        // 1. input chunk, coalesced 16 B per lane, into the padded raw tile
-        __syncthreads();
+        // 1. this lane's run of 16 consecutive samples: 8 coalesced 16-byte loads
+        float2 ext0[10 + kRun]; // ext0[10 + t] = x[t]; ext0[0..9] = halo x[-10..-1]
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int u = i * 64 + lane;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (2 * u < valid)
-                v = *reinterpret_cast<const float4 *>(in + base + 2 * u);
-            raw[u + (u >> 3)] = v;
+            const float4 v = in[tile_unit(c, i, lane)];
+            ext0[10 + 2 * i] = make_float2(v.x, v.y);
+            ext0[10 + 2 * i + 1] = make_float2(v.z, v.w);
         }
-        __syncthreads();
+        float2 *x = ext0 + 10;
 
-        // 2. this lane's run of 16 consecutive samples
-        float2 x[kRun];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float4 v = raw[9 * lane + i];
-            x[2 * i] = make_float2(v.x, v.y);
-            x[2 * i + 1] = make_float2(v.z, v.w);
-        }
-
-        // 3. NCO: regenerate table[idx .. idx+16) from the checkpoint before it, and mix
+        // 2. NCO: regenerate table[idx .. idx+16) from the checkpoint before it, and mix
         //    (vfo.cpp:241: osc * sample, re = ac - bd, im = ad + bc).  The very first sample
         //    after start-up is multiplied by the LAST table entry (oscillator.cpp:30,39-50).
         int idx = phase_frame + base; // both < L
@@ -259,31 +275,145 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
             }
         }
 
-        // 4. mixed samples into A_0 (lane runs, 144-byte lane stride: conflict-free b128 writes)
-        float2 *A0 = lds;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int p = kCarry + lane * kRun + 2 * i;
-            *reinterpret_cast<float4 *>(A0 + pad0(p)) = make_float4(x[2 * i].x, x[2 * i].y, x[2 * i + 1].x, x[2 * i + 1].y);
-        }
-
         if (D.d == 0) {
             // no decimation: decimate[0] is the mixed stream itself
-            __syncthreads();
-            if (emit) {
+            if (D.out_tiled) {
+                if (emit && active) {
+                    float4 *o4 = reinterpret_cast<float4 *>(out);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int u = i * 64 + lane;
-                    if (2 * u < valid)
-                        *reinterpret_cast<float4 *>(out + base + 2 * u) =
-                            *reinterpret_cast<const float4 *>(A0 + pad0(kCarry + 2 * u));
+                    for (int i = 0; i < 8; ++i)
+                        o4[tile_unit(c, i, lane)] = make_float4(x[2 * i].x, x[2 * i].y, x[2 * i + 1].x, x[2 * i + 1].y);
+                }
+            } else {
+                // natural order wanted: transpose through LDS so the stores are coalesced
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    *reinterpret_cast<float4 *>(lds + pad0(lane * kRun + 2 * i)) =
+                        make_float4(x[2 * i].x, x[2 * i].y, x[2 * i + 1].x, x[2 * i + 1].y);
+                __syncthreads();
+                if (emit) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int u = i * 64 + lane;
+                        if (2 * u < valid)
+                            *reinterpret_cast<float4 *>(out + base + 2 * u) = *reinterpret_cast<const float4 *>(lds + pad0(2 * u));
+                    }
                 }
             }
-        } else {
-            // 5. the cascade
-            StageChain<EXACT, 0>::run(lds, D.d, out + (base >> D.d), emit, valid, lane,
-                                      last_chunk && W.c_end == nchunks, hb_save);
+            continue;
         }
+
+        // 3. stage 0 in registers.  Halo = the previous lane's x[6,8,10,11,12,13,14,15]
+        //    (one whole-wave DPP shift each); lane 0 takes the previous chunk's lane 63 from LDS.
+        __syncthreads(); // car0/car1 of the previous chunk (or the initial state) are visible
+        {
+            const float4 *c4 = reinterpret_cast<const float4 *>(car0); // broadcast reads
+            const float4 q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
+            ext0[0] = shr1(make_float2(q0.x, q0.y), x[6]);   // x[-10]
+            ext0[2] = shr1(make_float2(q0.z, q0.w), x[8]);   // x[-8]
+            ext0[4] = shr1(make_float2(q1.x, q1.y), x[10]);  // x[-6]
+            ext0[5] = shr1(make_float2(q1.z, q1.w), x[11]);  // x[-5]
+            ext0[6] = shr1(make_float2(q2.x, q2.y), x[12]);  // x[-4]
+            ext0[7] = shr1(make_float2(q2.z, q2.w), x[13]);  // x[-3]
+            ext0[8] = shr1(make_float2(q3.x, q3.y), x[14]);  // x[-2]
+            ext0[9] = shr1(make_float2(q3.z, q3.w), x[15]);  // x[-1]
+            ext0[1] = ext0[3] = make_float2(0.f, 0.f);       // x[-9], x[-7]: never read
+        }
+        float2 ext1[10 + 8]; // ext1[10 + t] = y[t] (stage-0 outputs of this lane), ext1[0..9] halo
+        float2 *y = ext1 + 10;
+        hb_regs<EXACT, 8>(ext0, y);
+        if (save && lane == lv) // next frame's stage-0 history: x[size-1-k], k = 1..10
+#pragma unroll
+            for (int k = 1; k <= kHbHist; ++k)
+                hb_save[0 * kHbHist + k - 1] = x[15 - k];
+
+        if (D.d == 1) {
+            if (emit && active) {
+                const int g = (base >> 1) + lane * 8;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 v = make_float4(y[2 * i].x, y[2 * i].y, y[2 * i + 1].x, y[2 * i + 1].y);
+                    const size_t pos = D.out_tiled ? tile_pos(g + 2 * i) : (size_t)(g + 2 * i);
+                    *reinterpret_cast<float4 *>(out + pos) = v;
+                }
+            }
+            __syncthreads(); // every lane has read car0
+            if (lane == 63) {
+                float4 *c4 = reinterpret_cast<float4 *>(car0);
+                c4[0] = make_float4(x[6].x, x[6].y, x[8].x, x[8].y);
+                c4[1] = make_float4(x[10].x, x[10].y, x[11].x, x[11].y);
+                c4[2] = make_float4(x[12].x, x[12].y, x[13].x, x[13].y);
+                c4[3] = make_float4(x[14].x, x[14].y, x[15].x, x[15].y);
+            }
+            continue;
+        }
+
+        // 4. stage 1 in registers.  Halo y[-8,-6,-5,-4,-3,-2,-1] = previous lane's y[0,2..7],
+        //    y[-10] = the lane before that one's y[6] (a second shift of the shifted y[6]).
+        {
+            const float4 *c4 = reinterpret_cast<const float4 *>(car1);
+            const float4 q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
+            ext1[2] = shr1(make_float2(q0.z, q0.w), y[0]);  // y[-8]
+            ext1[4] = shr1(make_float2(q1.x, q1.y), y[2]);  // y[-6]
+            ext1[5] = shr1(make_float2(q1.z, q1.w), y[3]);  // y[-5]
+            ext1[6] = shr1(make_float2(q2.x, q2.y), y[4]);  // y[-4]
+            ext1[7] = shr1(make_float2(q2.z, q2.w), y[5]);  // y[-3]
+            ext1[8] = shr1(make_float2(q3.x, q3.y), y[6]);  // y[-2]
+            ext1[9] = shr1(make_float2(q3.z, q3.w), y[7]);  // y[-1]
+            ext1[0] = shr1(make_float2(q0.x, q0.y), ext1[8]); // y[-10]
+            ext1[1] = ext1[3] = make_float2(0.f, 0.f);
+        }
+        float2 z[4];
+        hb_regs<EXACT, 4>(ext1, z);
+        if (save) { // next frame's stage-1 history: y[size1-1-k]
+            if (lane == lv)
+#pragma unroll
+                for (int k = 1; k <= 7; ++k)
+                    hb_save[1 * kHbHist + k - 1] = y[7 - k];
+            if (lane == lv - 1)
+#pragma unroll
+                for (int k = 8; k <= kHbHist; ++k)
+                    hb_save[1 * kHbHist + k - 1] = y[15 - k];
+        }
+        __syncthreads(); // every lane has read car0 and car1
+        if (lane == 63) {
+            float4 *c4 = reinterpret_cast<float4 *>(car0);
+            c4[0] = make_float4(x[6].x, x[6].y, x[8].x, x[8].y);
+            c4[1] = make_float4(x[10].x, x[10].y, x[11].x, x[11].y);
+            c4[2] = make_float4(x[12].x, x[12].y, x[13].x, x[13].y);
+            c4[3] = make_float4(x[14].x, x[14].y, x[15].x, x[15].y);
+            float4 *d4 = reinterpret_cast<float4 *>(car1);
+            d4[0].z = y[0].x, d4[0].w = y[0].y; // slot 1 (y[-8]); slot 0 comes from lane 62
+            d4[1] = make_float4(y[2].x, y[2].y, y[3].x, y[3].y);
+            d4[2] = make_float4(y[4].x, y[4].y, y[5].x, y[5].y);
+            d4[3] = make_float4(y[6].x, y[6].y, y[7].x, y[7].y);
+        }
+        if (lane == 62)
+            car1[0] = y[6];
+
+        if (D.d == 2) {
+            if (emit && active) {
+                const int g = (base >> 2) + lane * 4;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float4 v = make_float4(z[2 * i].x, z[2 * i].y, z[2 * i + 1].x, z[2 * i + 1].y);
+                    const size_t pos = D.out_tiled ? tile_pos(g + 2 * i) : (size_t)(g + 2 * i);
+                    *reinterpret_cast<float4 *>(out + pos) = v;
+                }
+            }
+            continue;
+        }
+
+        // 5. stages >= 2 in LDS: this lane's 4 stage-2 inputs go to A_2, then the generic stage
+        {
+            float2 *A2 = lds + stage_offset(2) + kCarry + lane * 4;
+            *reinterpret_cast<float4 *>(A2) = make_float4(z[0].x, z[0].y, z[1].x, z[1].y);
+            *reinterpret_cast<float4 *>(A2 + 2) = make_float4(z[2].x, z[2].y, z[3].x, z[3].y);
+        }
+        for (int s = kRegStages; s < D.d; ++s)
+            hb_stage_lds<EXACT>(lds + stage_offset(s), lds + stage_offset(s + 1), out, base >> D.d, D.out_tiled != 0, s + 1 == D.d, emit,
+                                valid >> s, lane, save, hb_save + s * kHbHist);
     }
 }
 

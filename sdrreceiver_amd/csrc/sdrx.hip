@@ -61,6 +61,7 @@ struct Node {
 
 struct Launch1 { // one k_mix_decimate launch (a tree level)
     int kind;
+    int level;
     int n_work;
     int lds_bytes;
     size_t off_work; // arena offset of K1Work[]
@@ -96,7 +97,8 @@ struct sdrx_ctx {
     size_t arena_bytes = 0;
     unsigned char *d_pay = nullptr, *h_pay = nullptr;
     size_t pay_bytes = 0;
-    float2 *d_raw = nullptr; // staging for host-fed frames
+    float2 *d_raw = nullptr;       // staging for host-fed frames (natural order)
+    float2 *d_raw_tiled = nullptr; // the raw frame in tile layout: input of the parent-less VFOs
     unsigned char *d_raw_u8 = nullptr;
     float *d_dc_state = nullptr;
     size_t raw_cap = 0;
@@ -217,10 +219,20 @@ template <bool EXACT>
 int enqueue_frame(sdrx_ctx *c, const float2 *raw)
 {
     const K1Vfo *k1 = reinterpret_cast<const K1Vfo *>(c->arena + c->off_k1vfo);
+    {
+        // natural-order raw frame -> tile layout (the layout every k_mix_decimate input has)
+        Bracket b(c, KIND_INGEST, 0);
+        const int n_pairs = c->root_frame / 2;
+        hipLaunchKernelGGL(k_ingest_f32, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream,
+                           reinterpret_cast<const float4 *>(raw), reinterpret_cast<float4 *>(c->d_raw_tiled), n_pairs);
+    }
     for (const Launch1 &L : c->l1) {
         Bracket b(c, L.kind, L.alg_bytes);
-        hipLaunchKernelGGL(k_mix_decimate<EXACT>, dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1,
-                           reinterpret_cast<const K1Work *>(c->arena + L.off_work), raw, c->frame_no);
+        const K1Work *w = reinterpret_cast<const K1Work *>(c->arena + L.off_work);
+        if (L.level == 0)
+            hipLaunchKernelGGL((k_mix_decimate<EXACT, 0>), dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1, w, c->frame_no);
+        else
+            hipLaunchKernelGGL((k_mix_decimate<EXACT, 1>), dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1, w, c->frame_no);
     }
     for (const LaunchB &L : c->lb) {
         Bracket b(c, L.kind, L.alg_bytes);
@@ -314,6 +326,8 @@ int sdrx_destroy(sdrx_ctx *c)
         (void)hipFree(c->d_raw);
     if (c->d_raw_u8)
         (void)hipFree(c->d_raw_u8);
+    if (c->d_raw_tiled)
+        (void)hipFree(c->d_raw_tiled);
     if (c->d_dc_state)
         (void)hipFree(c->d_dc_state);
     if (c->own_stream)
@@ -399,6 +413,9 @@ int sdrx_finalize(sdrx_ctx *c)
         if (d.samples_per_buffer % (1 << d.decimate_count))
             return fail(c, SDRX_EUNSUPPORTED, "vfo %d: samples_per_buffer %d not a multiple of 2^%d", i, d.samples_per_buffer,
                         d.decimate_count);
+        if (d.samples_per_buffer % kChunk != 0 && d.samples_per_buffer % kChunk < 256)
+            return fail(c, SDRX_EUNSUPPORTED, "vfo %d: samples_per_buffer %d leaves a last chunk shorter than 256 samples", i,
+                        d.samples_per_buffer);
         if ((long long)d.samples_per_buffer > (long long)d.fs)
             return fail(c, SDRX_EUNSUPPORTED, "vfo %d: a frame longer than one second of signal is not supported", i);
         n.n_f = d.samples_per_buffer >> d.decimate_count;
@@ -479,8 +496,8 @@ int sdrx_finalize(sdrx_ctx *c)
                 n.Hx = Hdemod; // the stream itself feeds the demodulator
             }
         }
-        for (int p = 0; p < 2; ++p)
-            n.off_stream[p] = plan.take(sizeof(float2) * (size_t)(n.Hx + n.n_f));
+        for (int p = 0; p < 2; ++p) // a stream that feeds children is kept in whole 1024-sample tiles
+            n.off_stream[p] = plan.take(sizeof(float2) * (n.leaf ? (size_t)(n.Hx + n.n_f) : align_up((size_t)n.n_f, kChunk)));
         if (late)
             for (int p = 0; p < 2; ++p)
                 n.off_z[p] = plan.take(sizeof(float2) * (size_t)(n.H + n.n_out));
@@ -522,10 +539,14 @@ int sdrx_finalize(sdrx_ctx *c)
         const Node &n = c->nodes[(size_t)i];
         const int nchunks = (n.d.samples_per_buffer + kChunk - 1) / kChunk;
         const int W = warmup_chunks(n.d.decimate_count);
-        const int min_seg = std::max(4, 6 * W);
         int nseg = c->opt_segments;
         if (nseg <= 0) {
-            const int want = (ncu * 12 + level_count[(size_t)n.level] - 1) / level_count[(size_t)n.level];
+            // enough waves to fill the chip (~16 per CU); a segment pays W warm-up chunks, so keep
+            // segments at least 6 W long -- unless the level has so few VFOs (the 2-3 main VFOs)
+            // that latency matters more than the redundant warm-up work.
+            const int want = (ncu * 16 + level_count[(size_t)n.level] - 1) / level_count[(size_t)n.level];
+            const bool few = (long long)level_count[(size_t)n.level] * nchunks / std::max(4, 6 * W) < (long long)ncu * 4;
+            const int min_seg = few ? std::max(1, W) : std::max(4, 6 * W);
             nseg = std::min(want, nchunks / min_seg);
         }
         nseg = std::max(1, std::min(nseg, nchunks / std::max(1, std::max(W, 1))));
@@ -545,8 +566,12 @@ int sdrx_finalize(sdrx_ctx *c)
     for (int lv = 0; lv < c->n_levels; ++lv) {
         Launch1 L;
         L.kind = lv == 0 ? KIND_MIX_ROOT : KIND_MIX_SUB;
+        L.level = lv;
         L.n_work = (int)works[(size_t)lv].size();
-        L.lds_bytes = k1_lds_bytes(level_maxd[(size_t)lv]);
+        bool need_tr = false;
+        for (const Node &n : c->nodes)
+            need_tr |= n.level == lv && n.d.decimate_count == 0 && n.leaf;
+        L.lds_bytes = k1_lds_bytes(level_maxd[(size_t)lv], need_tr);
         L.off_work = plan.take(sizeof(K1Work) * works[(size_t)lv].size());
         L.alg_bytes = 0;
         for (const Node &n : c->nodes)
@@ -613,6 +638,11 @@ int sdrx_finalize(sdrx_ctx *c)
     HIPCHK(c, hipHostMalloc(&c->h_pay, c->pay_bytes, hipHostMallocDefault));
     memset(c->h_pay, 0, c->pay_bytes);
 
+    {
+        const size_t raw_tiles = align_up((size_t)c->root_frame, kChunk);
+        HIPCHK(c, hipMalloc(&c->d_raw_tiled, raw_tiles * sizeof(float2)));
+        HIPCHK(c, hipMemsetAsync(c->d_raw_tiled, 0, raw_tiles * sizeof(float2), c->stream));
+    }
     auto P = [&](size_t off) { return c->arena + off; };
     std::vector<K1Vfo> k1((size_t)N);
     std::vector<NcoInit> jobs((size_t)N);
@@ -625,7 +655,7 @@ int sdrx_finalize(sdrx_ctx *c)
                 const Node &pn = c->nodes[(size_t)n.d.parent_id];
                 k.in[p] = reinterpret_cast<const float2 *>(P(pn.off_stream[p])) + pn.Hx;
             } else {
-                k.in[p] = nullptr; // raw frame, passed per launch
+                k.in[p] = c->d_raw_tiled;
             }
             k.out[p] = reinterpret_cast<float2 *>(P(n.off_stream[p])) + n.Hx;
             k.hb[p] = reinterpret_cast<float2 *>(P(n.off_hb[p]));
@@ -636,6 +666,7 @@ int sdrx_finalize(sdrx_ctx *c)
         k.n_in = n.d.samples_per_buffer;
         k.d = n.d.decimate_count;
         k.L = n.d.fs;
+        k.out_tiled = n.leaf ? 0 : 1;
         jobs[(size_t)i] = NcoInit{reinterpret_cast<float2 *>(P(n.off_cp)), n.rot_re, n.rot_im, n.d.fs, 0};
     }
     for (auto &pe : p2a) {
@@ -843,9 +874,22 @@ int sdrx_get_stream(sdrx_ctx *c, int id, float *out, int max_complex, int *n_ret
     const int par = (int)((c->frame_no - 1) & 1ull);
     const int cnt = std::min(max_complex, n.n_f);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (out && cnt > 0)
-        HIPCHK(c, hipMemcpy(out, c->arena + n.off_stream[par] + sizeof(float2) * (size_t)n.Hx, sizeof(float2) * (size_t)cnt,
-                            hipMemcpyDeviceToHost));
+    if (out && cnt > 0) {
+        if (n.leaf) {
+            HIPCHK(c, hipMemcpy(out, c->arena + n.off_stream[par] + sizeof(float2) * (size_t)n.Hx, sizeof(float2) * (size_t)cnt,
+                                hipMemcpyDeviceToHost));
+        } else {
+            // tile layout on the device: undo it for the caller (fftData carries natural order)
+            const size_t total = align_up((size_t)n.n_f, kChunk);
+            std::vector<float2> tmp(total);
+            HIPCHK(c, hipMemcpy(tmp.data(), c->arena + n.off_stream[par], sizeof(float2) * total, hipMemcpyDeviceToHost));
+            float2 *o = reinterpret_cast<float2 *>(out);
+            for (int g = 0; g < cnt; ++g) {
+                const int ch = g >> 10, r = g & 1023, ln = r >> 4, i = r & 15;
+                o[g] = tmp[(size_t)ch * 1024 + (size_t)(i >> 1) * 128 + (size_t)ln * 2 + (size_t)(i & 1)];
+            }
+        }
+    }
     if (n_ret)
         *n_ret = n.n_f;
     return SDRX_OK;

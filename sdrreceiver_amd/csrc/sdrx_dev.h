@@ -17,15 +17,15 @@ constexpr int kMaxFir = 256;        // longest low-pass the demod kernels stage 
 
 // ---- mix + half-band cascade (one per VFO) ---------------------------------------------------
 struct K1Vfo {
-    const float2 *in[2];   // input stream (sample 0 of the frame) per frame parity; null = raw frame arg
-    float2 *out[2];        // decimate[d] of this frame, per frame parity
+    const float2 *in[2];   // input stream in TILE LAYOUT (see kernels.hip) per frame parity
+    float2 *out[2];        // decimate[d] of this frame, per frame parity (tile layout iff out_tiled)
     const float2 *cp;      // NCO checkpoints: cp[j] = table[16 j - 1], cp[0] = (1,0), cp[L/16] = table[L-1]
     float2 *hb[2];         // half-band history per frame parity: [d][10], entry k-1 = x[-k]
     float rot_re, rot_im;  // NCO rotation (float cos, float sin of the double angle)
     int n_in;              // complex samples per frame
     int d;                 // half-band stages
     int L;                 // NCO table length = (int)fs
-    int pad_;
+    int out_tiled;         // 1: children consume the output (tile layout); 0: natural order for the demod
 };
 
 // One wave's job: chunks [c_begin, c_end) of one VFO-frame; chunks before c_first_out only warm
