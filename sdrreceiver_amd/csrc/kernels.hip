@@ -21,6 +21,35 @@
 
 namespace sdrx {
 
+// Pointers that come out of a descriptor in memory are generic ("flat") to the compiler.  They
+// all point into HBM: these helpers say so, so that accesses become global_load/global_store
+// (or s_load for wave-uniform read-only data) instead of flat_* instructions.
+#define SDRX_AS1 __attribute__((address_space(1)))
+using v2f = float __attribute__((ext_vector_type(2)));
+using v4f = float __attribute__((ext_vector_type(4)));
+using v4s = short __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float gld(const float *p) { return *(const SDRX_AS1 float *)p; }
+__device__ __forceinline__ float2 gld2(const float2 *p)
+{
+    const v2f v = *(const SDRX_AS1 v2f *)p;
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float4 gld4(const float4 *p)
+{
+    const v4f v = *(const SDRX_AS1 v4f *)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gst2(float2 *p, float2 a)
+{
+    v2f v = {a.x, a.y};
+    *(SDRX_AS1 v2f *)p = v;
+}
+__device__ __forceinline__ void gst4(float4 *p, float4 a)
+{
+    v4f v = {a.x, a.y, a.z, a.w};
+    *(SDRX_AS1 v4f *)p = v;
+}
+
 // ------------------------------------------------------------------------------------ NCO
 // One step of the reference's table recurrence (oscillator.cpp:20-28): v *= rot (complex
 // product re = ac - bd, im = ad + bc), then v *= 1.95f - |v|^2.  Strict fp32, no FMA.
@@ -160,12 +189,12 @@ __device__ __forceinline__ void hb_stage_lds(float2 *__restrict__ A, float2 *__r
         if (!last)
             B[kCarry + j] = y;
         else if (emit)
-            gout[tiled ? tile_pos(gbase + j) : (size_t)(gbase + j)] = y;
+            gst2(gout + (tiled ? tile_pos(gbase + j) : (size_t)(gbase + j)), y);
     }
     __syncthreads(); // all window reads done before the carry is overwritten
     // FIRQueueBackToFront (dsp.cpp:163-173) at the end of the FRAME: x[-k] := x[size-1-k]
     if (save && lane < kHbHist)
-        hbsave[lane] = A[kCarry + cnt - 2 - lane];
+        gst2(hbsave + lane, A[kCarry + cnt - 2 - lane]);
     float2 t;
     if (lane < kCarry)
         t = A[cnt + lane]; // the last 16 of [carry | data]
@@ -222,13 +251,13 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
     // warm-up chunks until every stage's window holds real samples again.
     if (lane < 8) {
         const int k = halo_k(lane);
-        car0[lane] = (from_state && D.d > 0) ? hb_load[0 * kHbHist + k - 1] : make_float2(0.f, 0.f);
-        car1[lane] = (from_state && D.d > 1) ? hb_load[1 * kHbHist + k - 1] : make_float2(0.f, 0.f);
+        car0[lane] = (from_state && D.d > 0) ? gld2(hb_load + 0 * kHbHist + k - 1) : make_float2(0.f, 0.f);
+        car1[lane] = (from_state && D.d > 1) ? gld2(hb_load + 1 * kHbHist + k - 1) : make_float2(0.f, 0.f);
     }
     for (int s = kRegStages; s < D.d; ++s)
         if (lane < kCarry) {
             const int k = kCarry - lane; // carry position `lane` is x[-k]
-            lds[stage_offset(s) + lane] = (from_state && k <= kHbHist) ? hb_load[s * kHbHist + k - 1] : make_float2(0.f, 0.f);
+            lds[stage_offset(s) + lane] = (from_state && k <= kHbHist) ? gld2(hb_load + s * kHbHist + k - 1) : make_float2(0.f, 0.f);
         }
     const int phase_frame = (int)((frame_no * (unsigned long long)D.n_in) % (unsigned long long)D.L);
 
@@ -244,7 +273,7 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
         float2 ext0[10 + kRun]; // ext0[10 + t] = x[t]; ext0[0..9] = halo x[-10..-1]
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float4 v = in[tile_unit(c, i, lane)];
+            const float4 v = gld4(in + tile_unit(c, i, lane));
             ext0[10 + 2 * i] = make_float2(v.x, v.y);
             ext0[10 + 2 * i + 1] = make_float2(v.z, v.w);
         }
@@ -257,14 +286,14 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
         idx -= idx >= D.L ? D.L : 0;
         idx += lane * kRun;           // L >= kChunk (checked by sdrx_finalize)
         idx -= idx >= D.L ? D.L : 0;
-        float2 o = D.cp[idx >> 4];
+        float2 o = gld2(D.cp + (idx >> 4));
         const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
 #pragma unroll
         for (int i = 0; i < kRun; ++i) {
             o = nco_step(o, D.rot_re, D.rot_im);
             float2 m = o;
             if (i == 0 && first_ever)
-                m = D.cp[D.L >> 4];
+                m = gld2(D.cp + (D.L >> 4));
             const float a = m.x, b = m.y, cc = x[i].x, dd = x[i].y;
             if (EXACT) {
                 x[i].x = a * cc - b * dd;
@@ -282,7 +311,7 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
                     float4 *o4 = reinterpret_cast<float4 *>(out);
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        o4[tile_unit(c, i, lane)] = make_float4(x[2 * i].x, x[2 * i].y, x[2 * i + 1].x, x[2 * i + 1].y);
+                        gst4(o4 + tile_unit(c, i, lane), make_float4(x[2 * i].x, x[2 * i].y, x[2 * i + 1].x, x[2 * i + 1].y));
                 }
             } else {
                 // natural order wanted: transpose through LDS so the stores are coalesced
@@ -297,7 +326,7 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
                     for (int i = 0; i < 8; ++i) {
                         const int u = i * 64 + lane;
                         if (2 * u < valid)
-                            *reinterpret_cast<float4 *>(out + base + 2 * u) = *reinterpret_cast<const float4 *>(lds + pad0(2 * u));
+                            gst4(reinterpret_cast<float4 *>(out + base + 2 * u), *reinterpret_cast<const float4 *>(lds + pad0(2 * u)));
                     }
                 }
             }
@@ -326,7 +355,7 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
         if (save && lane == lv) // next frame's stage-0 history: x[size-1-k], k = 1..10
 #pragma unroll
             for (int k = 1; k <= kHbHist; ++k)
-                hb_save[0 * kHbHist + k - 1] = x[15 - k];
+                gst2(hb_save + 0 * kHbHist + k - 1, x[15 - k]);
 
         if (D.d == 1) {
             if (emit && active) {
@@ -335,7 +364,7 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
                 for (int i = 0; i < 4; ++i) {
                     const float4 v = make_float4(y[2 * i].x, y[2 * i].y, y[2 * i + 1].x, y[2 * i + 1].y);
                     const size_t pos = D.out_tiled ? tile_pos(g + 2 * i) : (size_t)(g + 2 * i);
-                    *reinterpret_cast<float4 *>(out + pos) = v;
+                    gst4(reinterpret_cast<float4 *>(out + pos), v);
                 }
             }
             __syncthreads(); // every lane has read car0
@@ -370,11 +399,11 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
             if (lane == lv)
 #pragma unroll
                 for (int k = 1; k <= 7; ++k)
-                    hb_save[1 * kHbHist + k - 1] = y[7 - k];
+                    gst2(hb_save + 1 * kHbHist + k - 1, y[7 - k]);
             if (lane == lv - 1)
 #pragma unroll
                 for (int k = 8; k <= kHbHist; ++k)
-                    hb_save[1 * kHbHist + k - 1] = y[15 - k];
+                    gst2(hb_save + 1 * kHbHist + k - 1, y[15 - k]);
         }
         __syncthreads(); // every lane has read car0 and car1
         if (lane == 63) {
@@ -399,7 +428,7 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
                 for (int i = 0; i < 2; ++i) {
                     const float4 v = make_float4(z[2 * i].x, z[2 * i].y, z[2 * i + 1].x, z[2 * i + 1].y);
                     const size_t pos = D.out_tiled ? tile_pos(g + 2 * i) : (size_t)(g + 2 * i);
-                    *reinterpret_cast<float4 *>(out + pos) = v;
+                    gst4(reinterpret_cast<float4 *>(out + pos), v);
                 }
             }
             continue;
@@ -454,12 +483,12 @@ __global__ __launch_bounds__(256) void k_late_decimate(const K2aVfo *__restrict_
     // history for the next frame: the last Hx entries of [hist | data]
     if (blk == 0)
         for (int j = tid; j < D.Hx; j += 256)
-            xnext[j] = xbase[D.n + j];
+            gst2(xnext + j, gld2(xbase + D.n + j));
     const int lo = D.L * k0 - D.ndec;              // first input index needed (>= -Hx)
     const int span = D.L * 255 + D.ndec;           // indices lo .. lo+span-1 feed the 256 outputs
     for (int t = tid; t < span; t += 256) {
         const int idx = lo + t;
-        sx[t] = idx < D.n ? x[idx] : make_float2(0.f, 0.f);
+        sx[t] = idx < D.n ? gld2(x + idx) : make_float2(0.f, 0.f);
     }
     __syncthreads();
     const int k = k0 + tid;
@@ -469,18 +498,18 @@ __global__ __launch_bounds__(256) void k_late_decimate(const K2aVfo *__restrict_
     float ar = 0.f, ai = 0.f;
     if (EXACT) {
         for (int i = 0; i < D.ndec; ++i) {
-            const float h = D.taps[i];
+            const float h = gld(D.taps + i);
             ar = ar + h * w[i].x;
             ai = ai + h * w[i].y;
         }
     } else {
         for (int i = 0; i < D.ndec; ++i) {
-            const float h = D.taps[i];
+            const float h = gld(D.taps + i);
             ar = fmaf(h, w[i].x, ar);
             ai = fmaf(h, w[i].y, ai);
         }
     }
-    zout[k] = make_float2(ar, ai);
+    gst2(zout + k, make_float2(ar, ai));
 }
 
 // USB demodulation + optional audio low-pass + int16 (vfo.cpp:300-332):
@@ -491,89 +520,164 @@ __global__ __launch_bounds__(256) void k_late_decimate(const K2aVfo *__restrict_
 //   usb'[m] = sum_{i<N} hu[i] usb[m-N+i]                  FIR::FIRUpdateAndProcess, newest excluded
 //   out[m]  = short(usb' * gain * 32768.0)                float product, then double
 // Only the 62 odd-index Hilbert taps are non-zero (the even ones are exactly 0.0f and adding
-// 0*x leaves a float sum unchanged), so the sum runs over those, in index order.
-// 256 outputs per block; stream window (I and Q planes) and the usb window sit in LDS.
+// 0*x leaves a float sum unchanged), so the sum runs over those, in index order:
+//   sum = sum_{s<62} hnz[s] Q[m - 123 + 2 s].
+//
+// Blocking: one 256-thread block = 1024 outputs of one VFO.  Outputs of equal parity share their
+// Q samples, so Q is staged in LDS as two parity planes and a thread computes 4 same-parity
+// outputs from one contiguous run of 65 plane entries (17 ds_read_b128 for 248 MACs); the taps
+// are wave-uniform scalar loads held in SGPRs.  The low-pass then takes 4 consecutive outputs per
+// thread from the usb values parked in LDS, taps broadcast from LDS.  EXACT keeps one accumulator
+// per output and the reference's summation order (4 independent chains per thread give the ILP).
+constexpr int kDemodTile = 1024;
+constexpr int kPlaneLen = (kDemodTile + kMaxFir + kHilbert + 1) / 2 + 8;
+
 template <bool EXACT>
 __global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfos, int blocks_per_vfo,
                                                    unsigned long long frame_no)
 {
-    __shared__ float sI[256 + kMaxFir + 128];
-    __shared__ float sQ[256 + kMaxFir + 128];
-    __shared__ float sU[256 + kMaxFir];
+    __shared__ __attribute__((aligned(16))) float sP0[kPlaneLen + 4]; // even offsets from `lo`, stored shifted by +3
+    __shared__ __attribute__((aligned(16))) float sP1[kPlaneLen + 4]; // odd offsets
+    __shared__ __attribute__((aligned(16))) float sI[kDemodTile + kMaxFir + 8];
+    __shared__ __attribute__((aligned(16))) float sU[kDemodTile + kMaxFir + 16];
+    __shared__ __attribute__((aligned(16))) float sH[kMaxFir + 16];
     const K2Vfo *Dp = vfos + blockIdx.x / blocks_per_vfo;
     const int blk = blockIdx.x % blocks_per_vfo;
     const int par = (int)(frame_no & 1ull);
     const int tid = threadIdx.x;
     struct {
-        const float *hilbert, *lpf;
+        const float *hnz, *lpf;
         short *pay;
         float *prequant;
         float gain;
         int H, n, nlpf;
-    } D = {Dp->hilbert, Dp->lpf, Dp->pay, Dp->prequant, Dp->gain, Dp->H, Dp->n, Dp->nlpf};
+    } D = {Dp->hnz, Dp->lpf_pad, Dp->pay, Dp->prequant, Dp->gain, Dp->H, Dp->n, Dp->nlpf};
     const float2 *sbase = Dp->s[par];
     float2 *snext = Dp->s_next[par];
-    const int m0 = blk * 256;
+    const int m0 = blk * kDemodTile;
     if (m0 >= D.n && blk != 0)
         return;
-    if (blk == 0)
+    // The 62 Hilbert taps, read before this kernel has stored anything so the compiler can use
+    // wave-uniform scalar loads and keep them in SGPRs for the whole block.
+    float hnz[kHilbertNz];
+#pragma unroll
+    for (int s = 0; s < kHilbertNz; ++s)
+        hnz[s] = gld(D.hnz + s);
+    if (D.nlpf > 0)
+        for (int j = tid; j < D.nlpf + 15; j += 256)
+            sH[j] = gld(D.lpf + j);
+    if (blk == 0) // history for the next frame: the last H entries of [hist | data]
         for (int j = tid; j < D.H; j += 256)
-            snext[j] = sbase[D.n + j];
+            gst2(snext + j, gld2(sbase + D.n + j));
     const float2 *z = sbase + D.H; // sample 0 of this frame
     const int N = D.nlpf;
-    const int lo = m0 - N - (kHilbert - 1); // first stream index needed (>= -H)
-    const int span = 256 + N + (kHilbert - 1);
-    for (int t = tid; t < span; t += 256) {
-        const int idx = lo + t;
-        float2 v = idx < D.n ? z[idx] : make_float2(0.f, 0.f);
-        sI[t] = v.x;
-        sQ[t] = v.y;
+    const int E = N + (N & 1);                  // usb values m0-E .. m0+1023 are computed (t = 0 .. ntv-1)
+    const int ntv = kDemodTile + E;
+    const int lo = m0 - E - (kHilbert - 1);     // first stream index touched (>= -H)
+    const int nr = ntv + (kHilbert - 1);        // offsets r = idx - lo in [0, nr)
+    for (int r = tid; r < nr; r += 256) {
+        const int idx = lo + r;
+        const float2 v = idx < D.n ? gld2(z + idx) : make_float2(0.f, 0.f);
+        if (r & 1)
+            sP1[r >> 1] = v.y;
+        else
+            sP0[(r >> 1) + 3] = v.y;
+        const int t = r - kDelay;               // I[u-62] for u = m0 - E + t
+        if (t >= 0 && t < ntv)
+            sI[t] = v.x;
     }
     __syncthreads();
-    // usb for indices m0-N .. m0+255  (u = index - (m0-N))
-    for (int u = tid; u < 256 + N; u += 256) {
-        const float *q = sQ + u; // q[i] = Q[mu - 124 + i]
-        float acc = 0.f;
-        if (EXACT) {
-#pragma unroll 4
-            for (int i = 1; i < kHilbert; i += 2)
-                acc = acc + D.hilbert[i] * q[i];
-        } else {
-            float a0 = 0.f, a1 = 0.f;
-#pragma unroll 4
-            for (int i = 1; i < kHilbert - 2; i += 4) {
-                a0 = fmaf(D.hilbert[i], q[i], a0);
-                a1 = fmaf(D.hilbert[i + 2], q[i + 2], a1);
-            }
-            acc = a0 + a1; // 31 pairs (i, i+2), i = 1,5,..,121: all 62 odd taps 1..123
+
+    // ---- usb: Q index of tap s for value t is r = t + 1 + 2 s
+    const int p = tid >> 7, q = tid & 127;      // waves 0-1 take even t, waves 2-3 odd t
+    const int soff = (4 - (E - N)) & 3;         // sU shift that makes the low-pass reads 16-byte aligned
+    for (int tb = 0; tb < ntv; tb += kDemodTile) {
+        const int t0 = tb + p + 8 * q;          // this thread: t0, t0+2, t0+4, t0+6
+        if (t0 >= ntv)
+            continue;
+        const float *plane = p == 0 ? sP1 + (t0 >> 1) : sP0 + 3 + ((t0 + 1) >> 1);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 17; ++g) {
+            const float4 v4 = *reinterpret_cast<const float4 *>(plane + 4 * g);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int s = 4 * g + e - rr;
+                    if (s >= 0 && s < kHilbertNz) {
+                        if (EXACT)
+                            acc[rr] = acc[rr] + hnz[s] * v[e];
+                        else
+                            acc[rr] = fmaf(hnz[s], v[e], acc[rr]);
+                    }
+                }
         }
-        const float usb = (float)((double)sI[u + kDelay] - (double)acc);
-        sU[u] = usb;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int t = t0 + 2 * rr;
+            if (t < ntv)
+                sU[t + soff] = (float)((double)sI[t] - (double)acc[rr]);
+        }
     }
     __syncthreads();
-    const int m = m0 + tid;
+
+    // ---- audio low-pass (newest sample excluded) on 4 consecutive outputs, then int16
+    const int j0 = 4 * tid;
+    const int m = m0 + j0;
     if (m >= D.n)
         return;
-    float usb;
+    float u4[4];
     if (N > 0) {
-        const float *w = sU + tid; // w[i] = usb[m - N + i]
-        float acc = 0.f;
-        if (EXACT) {
-            for (int i = 0; i < N; ++i)
-                acc = acc + D.lpf[i] * w[i];
-        } else {
-            for (int i = 0; i < N; ++i)
-                acc = fmaf(D.lpf[i], w[i], acc);
+        // output j0+rr, tap i reads usb t = j0 + rr + (E-N) + i; sH[i+3] = hu[i], zeros around
+        const float *w = sU + soff + (E - N) + j0; // 16-byte aligned by the choice of soff
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const int groups = (N + 6) / 4;
+        for (int g = 0; g < groups; ++g) {
+            const float4 v4 = *reinterpret_cast<const float4 *>(w + 4 * g);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            const float4 ha = *reinterpret_cast<const float4 *>(sH + 4 * g), hb4 = *reinterpret_cast<const float4 *>(sH + 4 * g + 4);
+            const float h[8] = {ha.x, ha.y, ha.z, ha.w, hb4.x, hb4.y, hb4.z, hb4.w}; // h[k] = hu[4g + k - 3]
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    if (EXACT)
+                        acc[rr] = acc[rr] + h[e - rr + 3] * v[e];
+                    else
+                        acc[rr] = fmaf(h[e - rr + 3], v[e], acc[rr]);
+                }
         }
-        usb = acc;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            u4[rr] = acc[rr];
     } else {
-        usb = sU[tid];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            u4[rr] = sU[soff + j0 + rr];
     }
-    const float scaled = usb * D.gain;
-    const double pre = (double)scaled * 32768.0;
-    D.pay[m] = to_short(pre);
-    if (D.prequant)
-        D.prequant[m] = (float)pre; // exact: float * 2^15
+    short o4[4];
+    float pq[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const float scaled = u4[rr] * D.gain;
+        const double pre = (double)scaled * 32768.0;
+        o4[rr] = to_short(pre);
+        pq[rr] = (float)pre; // exact: float * 2^15
+    }
+    if (m + 3 < D.n) {
+        v4s o = {o4[0], o4[1], o4[2], o4[3]};
+        *(SDRX_AS1 v4s *)(D.pay + m) = o;
+        if (D.prequant)
+            gst4(reinterpret_cast<float4 *>(D.prequant + m), make_float4(pq[0], pq[1], pq[2], pq[3]));
+    } else {
+        for (int rr = 0; rr < 4 && m + rr < D.n; ++rr) {
+            *(SDRX_AS1 short *)(D.pay + m + rr) = o4[rr];
+            if (D.prequant)
+                *(SDRX_AS1 float *)(D.prequant + m + rr) = pq[rr];
+        }
+    }
 }
 
 // vfo::compress (vfo.cpp:389-424): cstyle 1 packs the high nibbles of (re/scalecomp)*128 and
@@ -594,7 +698,7 @@ __global__ __launch_bounds__(256) void k_compress(const K3Vfo *__restrict__ vfos
     } D = {Dp->pay, Dp->n, Dp->cstyle, Dp->scalecomp};
     const float2 *z = Dp->s[par];
     for (int i = blk * 256 + threadIdx.x; i < D.n; i += blocks_per_vfo * 256) {
-        const float2 v = z[i];
+        const float2 v = gld2(z + i);
         if (D.cstyle == 1) {
             const float sc = (float)D.scalecomp;
             const int re = to_schar((v.x / sc) * 128.0f);

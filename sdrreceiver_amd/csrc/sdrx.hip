@@ -50,9 +50,10 @@ struct Node {
     bool leaf = false;
     // designed taps (host copies for sdrx_get_taps)
     std::vector<float> lpf, dec, hilbert;
+    std::vector<float> lpf_pad, hnz; // device forms: zero-padded low-pass, compacted Hilbert
     // device placement (byte offsets into the arena)
     size_t off_cp = 0, off_hb[2] = {0, 0}, off_stream[2] = {0, 0}, off_z[2] = {0, 0}, off_preq = 0;
-    size_t off_lpf = 0, off_dec = 0, off_hilbert = 0;
+    size_t off_lpf = 0, off_dec = 0, off_hilbert = 0, off_hnz = 0;
     int H = 0, Hx = 0;
     size_t pay_off = 0; // into the payload buffer
     uint32_t pay_len = 0;
@@ -442,8 +443,20 @@ int sdrx_finalize(sdrx_ctx *c)
             if ((int)n.lpf.size() > kMaxFir)
                 return fail(c, SDRX_EUNSUPPORTED, "vfo %d: %zu-tap audio filter exceeds %d", i, n.lpf.size(), kMaxFir);
         }
-        if (d.demod_usb)
+        if (d.demod_usb) {
             design_hilbert(kHilbert, n.n_out, n.hilbert); // vfo.cpp:137: "Fs" = samplesOut
+            n.hnz.clear();
+            for (int t = 0; t < kHilbert; ++t) {
+                if (t & 1)
+                    n.hnz.push_back(n.hilbert[(size_t)t]);
+                else if (n.hilbert[(size_t)t] != 0.0f)
+                    return fail(c, SDRX_EUNSUPPORTED, "vfo %d: even Hilbert tap %d is not zero", i, t);
+            }
+            if (!n.lpf.empty()) {
+                n.lpf_pad.assign(n.lpf.size() + 3 + 12, 0.0f);
+                std::copy(n.lpf.begin(), n.lpf.end(), n.lpf_pad.begin() + 3);
+            }
+        }
         nco_rotation((double)d.fs, d.mixer_freq_hz, n.rot_re, n.rot_im);
         if (d.parent_id < 0) {
             n.level = 0;
@@ -488,7 +501,7 @@ int sdrx_finalize(sdrx_ctx *c)
             n.off_hb[p] = plan.take(sizeof(float2) * (size_t)std::max(1, d.decimate_count * kHbHist));
         n.H = n.Hx = 0;
         if (n.leaf && d.demod_usb) {
-            const int Hdemod = (int)align_up((size_t)(n.lpf.size() + kHilbert - 1), 4);
+            const int Hdemod = (int)align_up((size_t)(n.lpf.size() + 1 + kHilbert - 1), 4);
             if (late) {
                 n.Hx = (int)align_up(n.dec.size(), 4);
                 n.H = Hdemod;
@@ -501,8 +514,10 @@ int sdrx_finalize(sdrx_ctx *c)
         if (late)
             for (int p = 0; p < 2; ++p)
                 n.off_z[p] = plan.take(sizeof(float2) * (size_t)(n.H + n.n_out));
-        if (!n.lpf.empty())
-            n.off_lpf = place_taps(n.lpf);
+        if (!n.lpf_pad.empty())
+            n.off_lpf = place_taps(n.lpf_pad);
+        if (!n.hnz.empty())
+            n.off_hnz = place_taps(n.hnz);
         if (!n.dec.empty())
             n.off_dec = place_taps(n.dec);
         if (!n.hilbert.empty())
@@ -601,7 +616,7 @@ int sdrx_finalize(sdrx_ctx *c)
                 b2a[g] += 0; // intermediate stream only: no algorithmic bytes of its own
                 lds2a[g] = std::max(lds2a[g], (int)sizeof(float2) * (n.d.late_decimate * 255 + (int)n.dec.size()));
             }
-            const int g = (n.n_out + 255) / 256;
+            const int g = (n.n_out + kDemodTile - 1) / kDemodTile;
             p2.push_back({i, g, (int)g2[g].size()});
             g2[g].push_back(K2Vfo{});
             b2[g] += n.pay_len; // W_out of SURVEY.md 8d
@@ -692,8 +707,8 @@ int sdrx_finalize(sdrx_ctx *c)
             k.s[p] = reinterpret_cast<const float2 *>(P(late ? n.off_z[p] : n.off_stream[p]));
             k.s_next[p] = reinterpret_cast<float2 *>(P(late ? n.off_z[p ^ 1] : n.off_stream[p ^ 1]));
         }
-        k.hilbert = reinterpret_cast<const float *>(P(n.off_hilbert));
-        k.lpf = n.lpf.empty() ? nullptr : reinterpret_cast<const float *>(P(n.off_lpf));
+        k.hnz = reinterpret_cast<const float *>(P(n.off_hnz));
+        k.lpf_pad = n.lpf.empty() ? nullptr : reinterpret_cast<const float *>(P(n.off_lpf));
         k.pay = reinterpret_cast<short *>(c->d_pay + n.pay_off);
         k.prequant = (c->opt_prequant) ? reinterpret_cast<float *>(P(n.off_preq)) : nullptr;
         k.gain = n.d.gain;
@@ -922,7 +937,7 @@ int sdrx_get_taps(sdrx_ctx *c, int id, int which, float *out, int max, int *n_re
     if (!t)
         return fail(c, SDRX_EINVAL, "which must be 0, 1 or 2");
     // read back what the kernels actually use (device copy), not the host vector
-    const size_t off = which == 0 ? n.off_lpf : which == 1 ? n.off_dec : n.off_hilbert;
+    const size_t off = which == 0 ? n.off_lpf + 3 * sizeof(float) : which == 1 ? n.off_dec : n.off_hilbert;
     const int cnt = std::min(max, (int)t->size());
     if (out && cnt > 0)
         HIPCHK(c, hipMemcpy(out, c->arena + off, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost));

@@ -50,8 +50,8 @@ struct K2aVfo {
 struct K2Vfo {
     const float2 *s[2];     // [hist H | data n] per parity
     float2 *s_next[2];
-    const float *hilbert;   // 125 taps
-    const float *lpf;       // nlpf taps or null
+    const float *hnz;       // the 62 non-zero Hilbert taps hp[1], hp[3], ..., hp[123]
+    const float *lpf_pad;   // audio low-pass taps with 3 zeros in front and >= 8 behind, or null
     short *pay;             // n int16
     float *prequant;        // optional n floats
     float gain;
