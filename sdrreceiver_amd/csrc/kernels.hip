@@ -50,6 +50,33 @@ __device__ __forceinline__ void gst4(float4 *p, float4 a)
     *(SDRX_AS1 v4f *)p = v;
 }
 
+// ---- packed complex arithmetic ------------------------------------------------------------------
+// Measured on MI355X (tools/valu_probe.hip): a plain fp32 VALU instruction issues every ~4.1 cycles
+// per wave, a packed v_pk_{mul,add,fma}_f32 every ~4.4 -- so complex (re, im) pairs are kept as
+// native 2-vectors and every operation is ONE packed instruction on both components.  Each packed
+// lane is an ordinary IEEE fp32 operation, so EXACT results are unchanged.
+__device__ __forceinline__ v2f xx(v2f a) { return __builtin_shufflevector(a, a, 0, 0); }
+__device__ __forceinline__ v2f yy(v2f a) { return __builtin_shufflevector(a, a, 1, 1); }
+__device__ __forceinline__ v2f yx(v2f a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ v2f lo2(v4f a) { return __builtin_shufflevector(a, a, 0, 1); }
+__device__ __forceinline__ v2f hi2(v4f a) { return __builtin_shufflevector(a, a, 2, 3); }
+__device__ __forceinline__ v4f cat2(v2f a, v2f b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); }
+// (a.x b.x - a.y b.y, a.x b.y + a.y b.x) with every product and the final sum/difference rounded
+// separately, like libstdc++'s complex<float> operator* (vfo.cpp:241, oscillator.cpp:22): the
+// combine is fma(t2, (-1,+1), t1) -- multiplying by +-1 is exact, so it is one rounding, i.e. a
+// subtraction in the low lane and an addition in the high lane.
+__device__ __forceinline__ v2f cmul(v2f a, v2f b)
+{
+    const v2f t1 = xx(a) * b;
+    const v2f t2 = yy(a) * yx(b);
+    const v2f pm = {-1.0f, 1.0f};
+    return __builtin_elementwise_fma(t2, pm, t1);
+}
+__device__ __forceinline__ v2f gldv2(const float2 *p) { return *(const SDRX_AS1 v2f *)p; }
+__device__ __forceinline__ v4f gldv4(const float4 *p) { return *(const SDRX_AS1 v4f *)p; }
+__device__ __forceinline__ void gstv2(float2 *p, v2f v) { *(SDRX_AS1 v2f *)p = v; }
+__device__ __forceinline__ void gstv4(float4 *p, v4f v) { *(SDRX_AS1 v4f *)p = v; }
+
 // ------------------------------------------------------------------------------------ NCO
 // One step of the reference's table recurrence (oscillator.cpp:20-28): v *= rot (complex
 // product re = ac - bd, im = ad + bc), then v *= 1.95f - |v|^2.  Strict fp32, no FMA.
@@ -59,6 +86,15 @@ __device__ __forceinline__ float2 nco_step(float2 v, float rc, float rs)
     float ni = v.x * rs + v.y * rc;
     float norm = 1.95f - (nr * nr + ni * ni);
     return make_float2(nr * norm, ni * norm);
+}
+
+// The same step on a packed (re, im) pair: 7 instructions instead of 12.
+__device__ __forceinline__ v2f nco_step_pk(v2f v, v2f rot)
+{
+    const v2f n = cmul(v, rot);          // nr = v.x rc - v.y rs, ni = v.x rs + v.y rc
+    const v2f sq = n * n;
+    const float norm = 1.95f - (sq.x + sq.y);
+    return n * norm;
 }
 
 // Replays the whole table once per VFO and keeps every 16th entry: cp[j] = table[16j-1]
@@ -115,6 +151,20 @@ __device__ __forceinline__ float hb_dot(float w0, float w2, float w4, float w5, 
     }
 }
 
+// the same on a packed complex sample (both components in one instruction each)
+template <bool EXACT>
+__device__ __forceinline__ v2f hb_dot2(v2f w0, v2f w2, v2f w4, v2f w5, v2f w6, v2f w8, v2f w10)
+{
+    if (EXACT) {
+        const v2f s = HB0 * (w0 + w10) + HB2 * (w2 + w8) + HB4 * (w4 + w6) + HB5 * w5;
+        return 0.0f + s;
+    } else {
+        const v2f h0 = {HB0, HB0}, h2 = {HB2, HB2}, h4 = {HB4, HB4};
+        return __builtin_elementwise_fma(h0, w0 + w10,
+                                         __builtin_elementwise_fma(h2, w2 + w8, __builtin_elementwise_fma(h4, w4 + w6, HB5 * w5)));
+    }
+}
+
 // ------------------------------------------------------------------------------------ streams
 // TILE LAYOUT.  Every cf32 stream that feeds k_mix_decimate is stored in tiles of 1024 samples:
 // tile c is 512 float4 units [i2 = 0..7][lane = 0..63]; unit (i2, lane) holds samples
@@ -147,7 +197,11 @@ __device__ __forceinline__ float shr1(float old, float src)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
                                                                  0x138, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float2 shr1(float2 old, float2 src) { return make_float2(shr1(old.x, src.x), shr1(old.y, src.y)); }
+__device__ __forceinline__ v2f shr1(v2f old, v2f src)
+{
+    v2f r = {shr1(old.x, src.x), shr1(old.y, src.y)};
+    return r;
+}
 
 // LDS of k_mix_decimate (per wave): two 8-entry carry rows for the register stages, then the
 // linear stage arrays A_s = [16 carry | 1024 >> s data] for the stages s >= 2 that run in LDS,
@@ -174,28 +228,25 @@ __host__ __device__ constexpr int k1_lds_bytes(int d, bool need_transpose)
 // One half-band stage of one chunk in LDS (stages >= 2): A = [16 carry | cnt data] -> B data, or
 // the output stream when this is the last stage.
 template <bool EXACT>
-__device__ __forceinline__ void hb_stage_lds(float2 *__restrict__ A, float2 *__restrict__ B, float2 *__restrict__ gout,
-                                             int gbase, bool tiled, bool last, bool emit, int cnt, int lane, bool save,
+__device__ __forceinline__ void hb_stage_lds(v2f *__restrict__ A, v2f *__restrict__ B, float2 *__restrict__ gout, int gbase,
+                                             bool tiled, bool last, bool emit, int cnt, int lane, bool save,
                                              float2 *__restrict__ hbsave)
 {
     __syncthreads(); // stage input (written by the previous phase) is visible
     const int nout = cnt >> 1;
     for (int j = lane; j < nout; j += 64) {
-        const float2 *w = A + kCarry + 2 * j - 10; // w[0..10], newest = input sample 2j of this chunk
-        float2 w0 = w[0], w2 = w[2], w4 = w[4], w5 = w[5], w6 = w[6], w8 = w[8], w10 = w[10];
-        float2 y;
-        y.x = hb_dot<EXACT>(w0.x, w2.x, w4.x, w5.x, w6.x, w8.x, w10.x);
-        y.y = hb_dot<EXACT>(w0.y, w2.y, w4.y, w5.y, w6.y, w8.y, w10.y);
+        const v2f *w = A + kCarry + 2 * j - 10; // w[0..10], newest = input sample 2j of this chunk
+        const v2f y = hb_dot2<EXACT>(w[0], w[2], w[4], w[5], w[6], w[8], w[10]);
         if (!last)
             B[kCarry + j] = y;
         else if (emit)
-            gst2(gout + (tiled ? tile_pos(gbase + j) : (size_t)(gbase + j)), y);
+            gstv2(gout + (tiled ? tile_pos(gbase + j) : (size_t)(gbase + j)), y);
     }
     __syncthreads(); // all window reads done before the carry is overwritten
     // FIRQueueBackToFront (dsp.cpp:163-173) at the end of the FRAME: x[-k] := x[size-1-k]
     if (save && lane < kHbHist)
-        gst2(hbsave + lane, A[kCarry + cnt - 2 - lane]);
-    float2 t;
+        gstv2(hbsave + lane, A[kCarry + cnt - 2 - lane]);
+    v2f t;
     if (lane < kCarry)
         t = A[cnt + lane]; // the last 16 of [carry | data]
     __syncthreads();
@@ -203,16 +254,15 @@ __device__ __forceinline__ void hb_stage_lds(float2 *__restrict__ A, float2 *__r
         A[lane] = t;
 }
 
-// 8 outputs of a register-resident stage from 16 own inputs + 8 halo values.
-// ext[k] holds input sample k-10 of this lane's run (k = 0..9 halo, only the needed ones set).
+// NOUT outputs of a register-resident stage.  ext[k] holds input sample k-10 of this lane's run
+// (k = 0..9: the halo, only the needed ones set).
 template <bool EXACT, int NOUT>
-__device__ __forceinline__ void hb_regs(const float2 *ext, float2 *y)
+__device__ __forceinline__ void hb_regs(const v2f *ext, v2f *y)
 {
 #pragma unroll
     for (int j = 0; j < NOUT; ++j) {
-        const float2 *w = ext + 2 * j; // w[t] = input sample 2j - 10 + t
-        y[j].x = hb_dot<EXACT>(w[0].x, w[2].x, w[4].x, w[5].x, w[6].x, w[8].x, w[10].x);
-        y[j].y = hb_dot<EXACT>(w[0].y, w[2].y, w[4].y, w[5].y, w[6].y, w[8].y, w[10].y);
+        const v2f *w = ext + 2 * j; // w[t] = input sample 2j - 10 + t
+        y[j] = hb_dot2<EXACT>(w[0], w[2], w[4], w[5], w[6], w[8], w[10]);
     }
 }
 
@@ -221,14 +271,17 @@ __device__ __forceinline__ constexpr int halo_k(int q) { return q == 0 ? 10 : q 
 
 // Fused NCO + mixer + half-band cascade.  One wave per workgroup, one workgroup per K1Work.
 // LEVEL only gives the root launch and the sub launches distinct kernel names in profiles.
+#ifndef SDRX_K1_MIN_WAVES
+#define SDRX_K1_MIN_WAVES 5 // waves per SIMD the register allocator must leave room for
+#endif
 template <bool EXACT, int LEVEL>
-__global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ vfos, const K1Work *__restrict__ work,
+__global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1Vfo *__restrict__ vfos, const K1Work *__restrict__ work,
                                                      unsigned long long frame_no)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2 *car0 = reinterpret_cast<float2 *>(smem);      // [8]
-    float2 *car1 = car0 + 8;                               // [8]
-    float2 *lds = reinterpret_cast<float2 *>(smem + kCarryBytes);
+    v2f *car0 = reinterpret_cast<v2f *>(smem);             // [8]
+    v2f *car1 = car0 + 8;                                  // [8]
+    v2f *lds = reinterpret_cast<v2f *>(smem + kCarryBytes);
 
     const K1Work W = work[blockIdx.x];
     const int lane = threadIdx.x;
@@ -236,28 +289,29 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
     const K1Vfo *Dp = vfos + W.vfo;
     struct {
         const float2 *cp;
-        float rot_re, rot_im;
         int n_in, d, L, out_tiled;
-    } D = {Dp->cp, Dp->rot_re, Dp->rot_im, Dp->n_in, Dp->d, Dp->L, Dp->out_tiled};
+    } D = {Dp->cp, Dp->n_in, Dp->d, Dp->L, Dp->out_tiled};
+    const v2f rot = {Dp->rot_re, Dp->rot_im};
     const float4 *in = reinterpret_cast<const float4 *>(Dp->in[par]);
     float2 *out = Dp->out[par];
     const float2 *hb_load = Dp->hb[par];
     float2 *hb_save = Dp->hb[par ^ 1];
     const int nchunks = (D.n_in + kChunk - 1) / kChunk;
     const bool from_state = W.c_begin == 0;
+    const v2f zero2 = {0.f, 0.f};
 
     // Filter state at the start of this segment: segment 0 continues from the previous frame's
     // history (zero at start-up, dsp.cpp:40-49); a later segment starts from zeros and runs
     // warm-up chunks until every stage's window holds real samples again.
     if (lane < 8) {
         const int k = halo_k(lane);
-        car0[lane] = (from_state && D.d > 0) ? gld2(hb_load + 0 * kHbHist + k - 1) : make_float2(0.f, 0.f);
-        car1[lane] = (from_state && D.d > 1) ? gld2(hb_load + 1 * kHbHist + k - 1) : make_float2(0.f, 0.f);
+        car0[lane] = (from_state && D.d > 0) ? gldv2(hb_load + 0 * kHbHist + k - 1) : zero2;
+        car1[lane] = (from_state && D.d > 1) ? gldv2(hb_load + 1 * kHbHist + k - 1) : zero2;
     }
     for (int s = kRegStages; s < D.d; ++s)
         if (lane < kCarry) {
             const int k = kCarry - lane; // carry position `lane` is x[-k]
-            lds[stage_offset(s) + lane] = (from_state && k <= kHbHist) ? gld2(hb_load + s * kHbHist + k - 1) : make_float2(0.f, 0.f);
+            lds[stage_offset(s) + lane] = (from_state && k <= kHbHist) ? gldv2(hb_load + s * kHbHist + k - 1) : zero2;
         }
     const int phase_frame = (int)((frame_no * (unsigned long long)D.n_in) % (unsigned long long)D.L);
 
@@ -270,38 +324,31 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
         const bool active = lane <= lv;
 
         // 1. this lane's run of 16 consecutive samples: 8 coalesced 16-byte loads
-        float2 ext0[10 + kRun]; // ext0[10 + t] = x[t]; ext0[0..9] = halo x[-10..-1]
+        v2f ext0[10 + kRun]; // ext0[10 + t] = x[t]; ext0[0..9] = halo x[-10..-1]
+        v2f *x = ext0 + 10;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float4 v = gld4(in + tile_unit(c, i, lane));
-            ext0[10 + 2 * i] = make_float2(v.x, v.y);
-            ext0[10 + 2 * i + 1] = make_float2(v.z, v.w);
+            const v4f v = gldv4(in + tile_unit(c, i, lane));
+            x[2 * i] = lo2(v);
+            x[2 * i + 1] = hi2(v);
         }
-        float2 *x = ext0 + 10;
 
         // 2. NCO: regenerate table[idx .. idx+16) from the checkpoint before it, and mix
-        //    (vfo.cpp:241: osc * sample, re = ac - bd, im = ad + bc).  The very first sample
-        //    after start-up is multiplied by the LAST table entry (oscillator.cpp:30,39-50).
+        //    (vfo.cpp:241: osc * sample).  The very first sample after start-up is multiplied
+        //    by the LAST table entry (oscillator.cpp:30,39-50).
         int idx = phase_frame + base; // both < L
         idx -= idx >= D.L ? D.L : 0;
         idx += lane * kRun;           // L >= kChunk (checked by sdrx_finalize)
         idx -= idx >= D.L ? D.L : 0;
-        float2 o = gld2(D.cp + (idx >> 4));
+        v2f o = gldv2(D.cp + (idx >> 4));
         const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
 #pragma unroll
         for (int i = 0; i < kRun; ++i) {
-            o = nco_step(o, D.rot_re, D.rot_im);
-            float2 m = o;
+            o = nco_step_pk(o, rot);
+            v2f m = o;
             if (i == 0 && first_ever)
-                m = gld2(D.cp + (D.L >> 4));
-            const float a = m.x, b = m.y, cc = x[i].x, dd = x[i].y;
-            if (EXACT) {
-                x[i].x = a * cc - b * dd;
-                x[i].y = a * dd + b * cc;
-            } else {
-                x[i].x = fmaf(a, cc, -(b * dd));
-                x[i].y = fmaf(a, dd, b * cc);
-            }
+                m = gldv2(D.cp + (D.L >> 4));
+            x[i] = cmul(m, x[i]);
         }
 
         if (D.d == 0) {
@@ -311,22 +358,21 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
                     float4 *o4 = reinterpret_cast<float4 *>(out);
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        gst4(o4 + tile_unit(c, i, lane), make_float4(x[2 * i].x, x[2 * i].y, x[2 * i + 1].x, x[2 * i + 1].y));
+                        gstv4(o4 + tile_unit(c, i, lane), cat2(x[2 * i], x[2 * i + 1]));
                 }
             } else {
                 // natural order wanted: transpose through LDS so the stores are coalesced
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    *reinterpret_cast<float4 *>(lds + pad0(lane * kRun + 2 * i)) =
-                        make_float4(x[2 * i].x, x[2 * i].y, x[2 * i + 1].x, x[2 * i + 1].y);
+                    *reinterpret_cast<v4f *>(lds + pad0(lane * kRun + 2 * i)) = cat2(x[2 * i], x[2 * i + 1]);
                 __syncthreads();
                 if (emit) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int u = i * 64 + lane;
                         if (2 * u < valid)
-                            gst4(reinterpret_cast<float4 *>(out + base + 2 * u), *reinterpret_cast<const float4 *>(lds + pad0(2 * u)));
+                            gstv4(reinterpret_cast<float4 *>(out + base + 2 * u), *reinterpret_cast<const v4f *>(lds + pad0(2 * u)));
                     }
                 }
             }
@@ -337,43 +383,42 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
         //    (one whole-wave DPP shift each); lane 0 takes the previous chunk's lane 63 from LDS.
         __syncthreads(); // car0/car1 of the previous chunk (or the initial state) are visible
         {
-            const float4 *c4 = reinterpret_cast<const float4 *>(car0); // broadcast reads
-            const float4 q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
-            ext0[0] = shr1(make_float2(q0.x, q0.y), x[6]);   // x[-10]
-            ext0[2] = shr1(make_float2(q0.z, q0.w), x[8]);   // x[-8]
-            ext0[4] = shr1(make_float2(q1.x, q1.y), x[10]);  // x[-6]
-            ext0[5] = shr1(make_float2(q1.z, q1.w), x[11]);  // x[-5]
-            ext0[6] = shr1(make_float2(q2.x, q2.y), x[12]);  // x[-4]
-            ext0[7] = shr1(make_float2(q2.z, q2.w), x[13]);  // x[-3]
-            ext0[8] = shr1(make_float2(q3.x, q3.y), x[14]);  // x[-2]
-            ext0[9] = shr1(make_float2(q3.z, q3.w), x[15]);  // x[-1]
-            ext0[1] = ext0[3] = make_float2(0.f, 0.f);       // x[-9], x[-7]: never read
+            const v4f *c4 = reinterpret_cast<const v4f *>(car0); // broadcast reads
+            const v4f q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
+            ext0[0] = shr1(lo2(q0), x[6]);   // x[-10]
+            ext0[2] = shr1(hi2(q0), x[8]);   // x[-8]
+            ext0[4] = shr1(lo2(q1), x[10]);  // x[-6]
+            ext0[5] = shr1(hi2(q1), x[11]);  // x[-5]
+            ext0[6] = shr1(lo2(q2), x[12]);  // x[-4]
+            ext0[7] = shr1(hi2(q2), x[13]);  // x[-3]
+            ext0[8] = shr1(lo2(q3), x[14]);  // x[-2]
+            ext0[9] = shr1(hi2(q3), x[15]);  // x[-1]
+            ext0[1] = ext0[3] = zero2;       // x[-9], x[-7]: never read
         }
-        float2 ext1[10 + 8]; // ext1[10 + t] = y[t] (stage-0 outputs of this lane), ext1[0..9] halo
-        float2 *y = ext1 + 10;
+        __syncthreads(); // every lane holds its halo: lane 63 may now leave ITS tail for the next chunk
+        if (lane == 63) {
+            v4f *c4 = reinterpret_cast<v4f *>(car0);
+            c4[0] = cat2(x[6], x[8]);
+            c4[1] = cat2(x[10], x[11]);
+            c4[2] = cat2(x[12], x[13]);
+            c4[3] = cat2(x[14], x[15]);
+        }
+        v2f ext1[10 + 8]; // ext1[10 + t] = y[t] (stage-0 outputs of this lane), ext1[0..9] halo
+        v2f *y = ext1 + 10;
         hb_regs<EXACT, 8>(ext0, y);
         if (save && lane == lv) // next frame's stage-0 history: x[size-1-k], k = 1..10
 #pragma unroll
             for (int k = 1; k <= kHbHist; ++k)
-                gst2(hb_save + 0 * kHbHist + k - 1, x[15 - k]);
+                gstv2(hb_save + 0 * kHbHist + k - 1, x[15 - k]);
 
         if (D.d == 1) {
             if (emit && active) {
                 const int g = (base >> 1) + lane * 8;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float4 v = make_float4(y[2 * i].x, y[2 * i].y, y[2 * i + 1].x, y[2 * i + 1].y);
                     const size_t pos = D.out_tiled ? tile_pos(g + 2 * i) : (size_t)(g + 2 * i);
-                    gst4(reinterpret_cast<float4 *>(out + pos), v);
+                    gstv4(reinterpret_cast<float4 *>(out + pos), cat2(y[2 * i], y[2 * i + 1]));
                 }
-            }
-            __syncthreads(); // every lane has read car0
-            if (lane == 63) {
-                float4 *c4 = reinterpret_cast<float4 *>(car0);
-                c4[0] = make_float4(x[6].x, x[6].y, x[8].x, x[8].y);
-                c4[1] = make_float4(x[10].x, x[10].y, x[11].x, x[11].y);
-                c4[2] = make_float4(x[12].x, x[12].y, x[13].x, x[13].y);
-                c4[3] = make_float4(x[14].x, x[14].y, x[15].x, x[15].y);
             }
             continue;
         }
@@ -381,54 +426,48 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
         // 4. stage 1 in registers.  Halo y[-8,-6,-5,-4,-3,-2,-1] = previous lane's y[0,2..7],
         //    y[-10] = the lane before that one's y[6] (a second shift of the shifted y[6]).
         {
-            const float4 *c4 = reinterpret_cast<const float4 *>(car1);
-            const float4 q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
-            ext1[2] = shr1(make_float2(q0.z, q0.w), y[0]);  // y[-8]
-            ext1[4] = shr1(make_float2(q1.x, q1.y), y[2]);  // y[-6]
-            ext1[5] = shr1(make_float2(q1.z, q1.w), y[3]);  // y[-5]
-            ext1[6] = shr1(make_float2(q2.x, q2.y), y[4]);  // y[-4]
-            ext1[7] = shr1(make_float2(q2.z, q2.w), y[5]);  // y[-3]
-            ext1[8] = shr1(make_float2(q3.x, q3.y), y[6]);  // y[-2]
-            ext1[9] = shr1(make_float2(q3.z, q3.w), y[7]);  // y[-1]
-            ext1[0] = shr1(make_float2(q0.x, q0.y), ext1[8]); // y[-10]
-            ext1[1] = ext1[3] = make_float2(0.f, 0.f);
+            const v4f *c4 = reinterpret_cast<const v4f *>(car1);
+            const v4f q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
+            ext1[2] = shr1(hi2(q0), y[0]);  // y[-8]
+            ext1[4] = shr1(lo2(q1), y[2]);  // y[-6]
+            ext1[5] = shr1(hi2(q1), y[3]);  // y[-5]
+            ext1[6] = shr1(lo2(q2), y[4]);  // y[-4]
+            ext1[7] = shr1(hi2(q2), y[5]);  // y[-3]
+            ext1[8] = shr1(lo2(q3), y[6]);  // y[-2]
+            ext1[9] = shr1(hi2(q3), y[7]);  // y[-1]
+            ext1[0] = shr1(lo2(q0), ext1[8]); // y[-10]
+            ext1[1] = ext1[3] = zero2;
         }
-        float2 z[4];
-        hb_regs<EXACT, 4>(ext1, z);
+        __syncthreads(); // every lane has read car1
+        if (lane == 63) {
+            car1[1] = y[0]; // slot 1 (y[-8]); slot 0 comes from lane 62
+            v4f *d4 = reinterpret_cast<v4f *>(car1);
+            d4[1] = cat2(y[2], y[3]);
+            d4[2] = cat2(y[4], y[5]);
+            d4[3] = cat2(y[6], y[7]);
+        }
+        if (lane == 62)
+            car1[0] = y[6];
         if (save) { // next frame's stage-1 history: y[size1-1-k]
             if (lane == lv)
 #pragma unroll
                 for (int k = 1; k <= 7; ++k)
-                    gst2(hb_save + 1 * kHbHist + k - 1, y[7 - k]);
+                    gstv2(hb_save + 1 * kHbHist + k - 1, y[7 - k]);
             if (lane == lv - 1)
 #pragma unroll
                 for (int k = 8; k <= kHbHist; ++k)
-                    gst2(hb_save + 1 * kHbHist + k - 1, y[15 - k]);
+                    gstv2(hb_save + 1 * kHbHist + k - 1, y[15 - k]);
         }
-        __syncthreads(); // every lane has read car0 and car1
-        if (lane == 63) {
-            float4 *c4 = reinterpret_cast<float4 *>(car0);
-            c4[0] = make_float4(x[6].x, x[6].y, x[8].x, x[8].y);
-            c4[1] = make_float4(x[10].x, x[10].y, x[11].x, x[11].y);
-            c4[2] = make_float4(x[12].x, x[12].y, x[13].x, x[13].y);
-            c4[3] = make_float4(x[14].x, x[14].y, x[15].x, x[15].y);
-            float4 *d4 = reinterpret_cast<float4 *>(car1);
-            d4[0].z = y[0].x, d4[0].w = y[0].y; // slot 1 (y[-8]); slot 0 comes from lane 62
-            d4[1] = make_float4(y[2].x, y[2].y, y[3].x, y[3].y);
-            d4[2] = make_float4(y[4].x, y[4].y, y[5].x, y[5].y);
-            d4[3] = make_float4(y[6].x, y[6].y, y[7].x, y[7].y);
-        }
-        if (lane == 62)
-            car1[0] = y[6];
+        v2f z[4];
+        hb_regs<EXACT, 4>(ext1, z);
 
         if (D.d == 2) {
             if (emit && active) {
                 const int g = (base >> 2) + lane * 4;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const float4 v = make_float4(z[2 * i].x, z[2 * i].y, z[2 * i + 1].x, z[2 * i + 1].y);
                     const size_t pos = D.out_tiled ? tile_pos(g + 2 * i) : (size_t)(g + 2 * i);
-                    gst4(reinterpret_cast<float4 *>(out + pos), v);
+                    gstv4(reinterpret_cast<float4 *>(out + pos), cat2(z[2 * i], z[2 * i + 1]));
                 }
             }
             continue;
@@ -436,9 +475,9 @@ __global__ __launch_bounds__(64) void k_mix_decimate(const K1Vfo *__restrict__ v
 
         // 5. stages >= 2 in LDS: this lane's 4 stage-2 inputs go to A_2, then the generic stage
         {
-            float2 *A2 = lds + stage_offset(2) + kCarry + lane * 4;
-            *reinterpret_cast<float4 *>(A2) = make_float4(z[0].x, z[0].y, z[1].x, z[1].y);
-            *reinterpret_cast<float4 *>(A2 + 2) = make_float4(z[2].x, z[2].y, z[3].x, z[3].y);
+            v2f *A2 = lds + stage_offset(2) + kCarry + lane * 4;
+            *reinterpret_cast<v4f *>(A2) = cat2(z[0], z[1]);
+            *reinterpret_cast<v4f *>(A2 + 2) = cat2(z[2], z[3]);
         }
         for (int s = kRegStages; s < D.d; ++s)
             hb_stage_lds<EXACT>(lds + stage_offset(s), lds + stage_offset(s + 1), out, base >> D.d, D.out_tiled != 0, s + 1 == D.d, emit,
@@ -460,13 +499,14 @@ __device__ __forceinline__ short to_short(double d)
 // NOT part of the sum ((N+1)-slot ring).  The phase counter restarts every frame and frames are
 // multiples of L, so k is frame-local.  256 outputs per block; the input window sits in LDS.
 template <bool EXACT>
-__global__ __launch_bounds__(256) void k_late_decimate(const K2aVfo *__restrict__ vfos, int blocks_per_vfo,
+__global__ __launch_bounds__(256) void k_late_decimate(const K2aVfo *__restrict__ vfos, const BlockWork *__restrict__ work,
                                                        unsigned long long frame_no)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *sx = reinterpret_cast<float2 *>(smem);
-    const K2aVfo *Dp = vfos + blockIdx.x / blocks_per_vfo;
-    const int blk = blockIdx.x % blocks_per_vfo;
+    const BlockWork bw = work[blockIdx.x];
+    const K2aVfo *Dp = vfos + bw.vfo;
+    const int blk = bw.blk;
     const int par = (int)(frame_no & 1ull);
     const int tid = threadIdx.x;
     struct {
@@ -533,7 +573,7 @@ constexpr int kDemodTile = 1024;
 constexpr int kPlaneLen = (kDemodTile + kMaxFir + kHilbert + 1) / 2 + 8;
 
 template <bool EXACT>
-__global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfos, int blocks_per_vfo,
+__global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfos, const BlockWork *__restrict__ work,
                                                    unsigned long long frame_no)
 {
     __shared__ __attribute__((aligned(16))) float sP0[kPlaneLen + 4]; // even offsets from `lo`, stored shifted by +3
@@ -541,8 +581,9 @@ __global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfo
     __shared__ __attribute__((aligned(16))) float sI[kDemodTile + kMaxFir + 8];
     __shared__ __attribute__((aligned(16))) float sU[kDemodTile + kMaxFir + 16];
     __shared__ __attribute__((aligned(16))) float sH[kMaxFir + 16];
-    const K2Vfo *Dp = vfos + blockIdx.x / blocks_per_vfo;
-    const int blk = blockIdx.x % blocks_per_vfo;
+    const BlockWork bw = work[blockIdx.x];
+    const K2Vfo *Dp = vfos + bw.vfo;
+    const int blk = bw.blk;
     const int par = (int)(frame_no & 1ull);
     const int tid = threadIdx.x;
     struct {
@@ -686,18 +727,19 @@ __device__ __forceinline__ int to_schar(float f)
 {
     return (int)(signed char)(unsigned char)(unsigned)(int)f;
 }
-__global__ __launch_bounds__(256) void k_compress(const K3Vfo *__restrict__ vfos, int blocks_per_vfo,
+__global__ __launch_bounds__(256) void k_compress(const K3Vfo *__restrict__ vfos, const BlockWork *__restrict__ work,
                                                   unsigned long long frame_no)
 {
-    const K3Vfo *Dp = vfos + blockIdx.x / blocks_per_vfo;
-    const int blk = blockIdx.x % blocks_per_vfo;
+    const BlockWork bw = work[blockIdx.x];
+    const K3Vfo *Dp = vfos + bw.vfo;
+    const int blk = bw.blk;
     const int par = (int)(frame_no & 1ull);
     struct {
         signed char *pay;
         int n, cstyle, scalecomp;
     } D = {Dp->pay, Dp->n, Dp->cstyle, Dp->scalecomp};
     const float2 *z = Dp->s[par];
-    for (int i = blk * 256 + threadIdx.x; i < D.n; i += blocks_per_vfo * 256) {
+    for (int i = blk * 4096 + threadIdx.x; i < min(D.n, (blk + 1) * 4096); i += 256) {
         const float2 v = gld2(z + i);
         if (D.cstyle == 1) {
             const float sc = (float)D.scalecomp;

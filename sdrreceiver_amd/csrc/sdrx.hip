@@ -68,10 +68,10 @@ struct Launch1 { // one k_mix_decimate launch (a tree level)
     size_t off_work; // arena offset of K1Work[]
     int64_t alg_bytes;
 };
-struct LaunchB { // block-per-256-outputs launches (late decimate / demod / compress)
+struct LaunchB { // block-per-tile launches (late decimate / demod / compress): one launch per kernel
     int kind;
-    int n_vfo, blocks_per_vfo;
-    size_t off_desc;
+    int n_blocks;
+    size_t off_desc, off_work;
     int lds_bytes;
     int64_t alg_bytes;
 };
@@ -237,16 +237,17 @@ int enqueue_frame(sdrx_ctx *c, const float2 *raw)
     }
     for (const LaunchB &L : c->lb) {
         Bracket b(c, L.kind, L.alg_bytes);
-        const dim3 grid(L.n_vfo * L.blocks_per_vfo);
+        const dim3 grid(L.n_blocks);
+        const BlockWork *w = reinterpret_cast<const BlockWork *>(c->arena + L.off_work);
         if (L.kind == KIND_LATE_DEC)
             hipLaunchKernelGGL(k_late_decimate<EXACT>, grid, dim3(256), L.lds_bytes, c->stream,
-                               reinterpret_cast<const K2aVfo *>(c->arena + L.off_desc), L.blocks_per_vfo, c->frame_no);
+                               reinterpret_cast<const K2aVfo *>(c->arena + L.off_desc), w, c->frame_no);
         else if (L.kind == KIND_DEMOD)
             hipLaunchKernelGGL(k_usb_demod<EXACT>, grid, dim3(256), 0, c->stream,
-                               reinterpret_cast<const K2Vfo *>(c->arena + L.off_desc), L.blocks_per_vfo, c->frame_no);
+                               reinterpret_cast<const K2Vfo *>(c->arena + L.off_desc), w, c->frame_no);
         else
             hipLaunchKernelGGL(k_compress, grid, dim3(256), 0, c->stream,
-                               reinterpret_cast<const K3Vfo *>(c->arena + L.off_desc), L.blocks_per_vfo, c->frame_no);
+                               reinterpret_cast<const K3Vfo *>(c->arena + L.off_desc), w, c->frame_no);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
@@ -550,21 +551,58 @@ int sdrx_finalize(sdrx_ctx *c)
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
             ncu = prop.multiProcessorCount;
     }
+    // Segmentation.  A work item is one wave walking `seglen` chunks (+ W warm-up chunks when it
+    // starts mid-frame).  The whole launch should be ONE resident round of equally long items:
+    // items <= slots (CUs x resident waves per CU, from the occupancy query) and the same seglen
+    // for every VFO of the level, so no CU sits idle behind a long straggler.
+    std::vector<int> level_seglen((size_t)c->n_levels, 0);
+    for (int lv = 0; lv < c->n_levels; ++lv) {
+        const int lds = k1_lds_bytes(level_maxd[(size_t)lv], false);
+        int per_cu = 0;
+        hipError_t oe = c->opt_exact
+            ? (lv == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mix_decimate<true, 0>, 64, (size_t)lds)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mix_decimate<true, 1>, 64, (size_t)lds))
+            : (lv == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mix_decimate<false, 0>, 64, (size_t)lds)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mix_decimate<false, 1>, 64, (size_t)lds));
+        if (oe != hipSuccess || per_cu <= 0)
+            per_cu = 16;
+        const long long slots = (long long)ncu * per_cu;
+        long long total = 0;
+        int max_chunks = 1, min_chunks = 1 << 30, Wmax = 0;
+        for (const Node &n : c->nodes)
+            if (n.level == lv) {
+                const int nc = (n.d.samples_per_buffer + kChunk - 1) / kChunk;
+                total += nc;
+                max_chunks = std::max(max_chunks, nc);
+                min_chunks = std::min(min_chunks, nc);
+                Wmax = std::max(Wmax, warmup_chunks(n.d.decimate_count));
+            }
+        auto items_at = [&](int seglen) {
+            long long it = 0;
+            for (const Node &n : c->nodes)
+                if (n.level == lv)
+                    it += ((n.d.samples_per_buffer + kChunk - 1) / kChunk + seglen - 1) / seglen;
+            return it;
+        };
+        int seglen;
+        if (total * 4 <= slots * std::max(4, 6 * Wmax)) {
+            // tiny level (the 2-3 main VFOs, or a small profile): latency matters, not redundancy
+            seglen = std::max(1, std::max(Wmax, (int)((total + slots - 1) / slots)));
+        } else if (total <= slots * (long long)max_chunks) {
+            seglen = std::max((int)((total + slots - 1) / slots), std::max(4, 6 * Wmax));
+            while (seglen < max_chunks && items_at(seglen) > slots)
+                ++seglen;
+        } else {
+            seglen = std::max(min_chunks, std::max(4, 6 * Wmax)); // many rounds: uniform item size, dynamic balance
+        }
+        level_seglen[(size_t)lv] = seglen;
+    }
     for (int i = 0; i < N; ++i) {
         const Node &n = c->nodes[(size_t)i];
         const int nchunks = (n.d.samples_per_buffer + kChunk - 1) / kChunk;
         const int W = warmup_chunks(n.d.decimate_count);
-        int nseg = c->opt_segments;
-        if (nseg <= 0) {
-            // enough waves to fill the chip (~16 per CU); a segment pays W warm-up chunks, so keep
-            // segments at least 6 W long -- unless the level has so few VFOs (the 2-3 main VFOs)
-            // that latency matters more than the redundant warm-up work.
-            const int want = (ncu * 16 + level_count[(size_t)n.level] - 1) / level_count[(size_t)n.level];
-            const bool few = (long long)level_count[(size_t)n.level] * nchunks / std::max(4, 6 * W) < (long long)ncu * 4;
-            const int min_seg = few ? std::max(1, W) : std::max(4, 6 * W);
-            nseg = std::min(want, nchunks / min_seg);
-        }
-        nseg = std::max(1, std::min(nseg, nchunks / std::max(1, std::max(W, 1))));
+        int nseg = c->opt_segments > 0 ? c->opt_segments : (nchunks + level_seglen[(size_t)n.level] - 1) / level_seglen[(size_t)n.level];
+        nseg = std::max(1, std::min(nseg, nchunks / std::max(1, W)));
         for (int s = 0; s < nseg; ++s) {
             K1Work w;
             w.vfo = i;
@@ -595,51 +633,55 @@ int sdrx_finalize(sdrx_ctx *c)
         c->l1.push_back(L);
     }
 
-    // ---- block-per-256-outputs launches, grouped by block count
-    std::map<int, std::vector<K2aVfo>> g2a;
-    std::map<int, std::vector<K2Vfo>> g2;
-    std::map<int, std::vector<K3Vfo>> g3;
-    std::map<int, int64_t> b2a, b2, b3;
-    std::map<int, int> lds2a;
-    // descriptors are filled after the arena exists (they hold absolute pointers): remember who goes where
-    struct Pending { int node; int group; int idx; };
-    std::vector<Pending> p2a, p2, p3;
+    // ---- block-per-tile launches: one launch per kernel, driven by a (vfo, tile) work list
+    std::vector<K2aVfo> d2a;
+    std::vector<K2Vfo> d2;
+    std::vector<K3Vfo> d3;
+    std::vector<BlockWork> w2a, w2, w3;
+    std::vector<int> n2a, n2, n3; // node index of each descriptor
+    int64_t b2a = 0, b2 = 0, b3 = 0;
+    int lds2a = 0;
     for (int i = 0; i < N; ++i) {
         Node &n = c->nodes[(size_t)i];
         if (!n.leaf)
             continue;
         if (n.d.demod_usb) {
             if (n.d.late_decimate > 0) {
-                const int g = (n.n_out + 255) / 256;
-                p2a.push_back({i, g, (int)g2a[g].size()});
-                g2a[g].push_back(K2aVfo{});
-                b2a[g] += 0; // intermediate stream only: no algorithmic bytes of its own
-                lds2a[g] = std::max(lds2a[g], (int)sizeof(float2) * (n.d.late_decimate * 255 + (int)n.dec.size()));
+                for (int b = 0; b < (n.n_out + 255) / 256; ++b)
+                    w2a.push_back({(int)d2a.size(), b});
+                n2a.push_back(i);
+                d2a.push_back(K2aVfo{});
+                lds2a = std::max(lds2a, (int)sizeof(float2) * (n.d.late_decimate * 255 + (int)n.dec.size()));
             }
-            const int g = (n.n_out + kDemodTile - 1) / kDemodTile;
-            p2.push_back({i, g, (int)g2[g].size()});
-            g2[g].push_back(K2Vfo{});
-            b2[g] += n.pay_len; // W_out of SURVEY.md 8d
+            for (int b = 0; b < (n.n_out + kDemodTile - 1) / kDemodTile; ++b)
+                w2.push_back({(int)d2.size(), b});
+            n2.push_back(i);
+            d2.push_back(K2Vfo{});
+            b2 += n.pay_len; // W_out of SURVEY.md 8d
         } else {
-            const int g = std::min(64, (n.n_f + 255) / 256);
-            p3.push_back({i, g, (int)g3[g].size()});
-            g3[g].push_back(K3Vfo{});
-            b3[g] += n.pay_len;
+            for (int b = 0; b < (n.n_f + 4095) / 4096; ++b)
+                w3.push_back({(int)d3.size(), b});
+            n3.push_back(i);
+            d3.push_back(K3Vfo{});
+            b3 += n.pay_len;
         }
     }
     c->lb.clear();
-    std::map<int, size_t> o2a, o2, o3;
-    for (auto &kv : g2a) {
-        o2a[kv.first] = plan.take(sizeof(K2aVfo) * kv.second.size());
-        c->lb.push_back({KIND_LATE_DEC, (int)kv.second.size(), kv.first, o2a[kv.first], lds2a[kv.first], b2a[kv.first]});
+    size_t o2a = 0, o2 = 0, o3 = 0, ow2a = 0, ow2 = 0, ow3 = 0;
+    if (!d2a.empty()) {
+        o2a = plan.take(sizeof(K2aVfo) * d2a.size());
+        ow2a = plan.take(sizeof(BlockWork) * w2a.size());
+        c->lb.push_back({KIND_LATE_DEC, (int)w2a.size(), o2a, ow2a, lds2a, b2a});
     }
-    for (auto &kv : g2) {
-        o2[kv.first] = plan.take(sizeof(K2Vfo) * kv.second.size());
-        c->lb.push_back({KIND_DEMOD, (int)kv.second.size(), kv.first, o2[kv.first], 0, b2[kv.first]});
+    if (!d2.empty()) {
+        o2 = plan.take(sizeof(K2Vfo) * d2.size());
+        ow2 = plan.take(sizeof(BlockWork) * w2.size());
+        c->lb.push_back({KIND_DEMOD, (int)w2.size(), o2, ow2, 0, b2});
     }
-    for (auto &kv : g3) {
-        o3[kv.first] = plan.take(sizeof(K3Vfo) * kv.second.size());
-        c->lb.push_back({KIND_COMPRESS, (int)kv.second.size(), kv.first, o3[kv.first], 0, b3[kv.first]});
+    if (!d3.empty()) {
+        o3 = plan.take(sizeof(K3Vfo) * d3.size());
+        ow3 = plan.take(sizeof(BlockWork) * w3.size());
+        c->lb.push_back({KIND_COMPRESS, (int)w3.size(), o3, ow3, 0, b3});
     }
     const size_t off_nco_jobs = plan.take(sizeof(NcoInit) * (size_t)N);
 
@@ -684,9 +726,9 @@ int sdrx_finalize(sdrx_ctx *c)
         k.out_tiled = n.leaf ? 0 : 1;
         jobs[(size_t)i] = NcoInit{reinterpret_cast<float2 *>(P(n.off_cp)), n.rot_re, n.rot_im, n.d.fs, 0};
     }
-    for (auto &pe : p2a) {
-        Node &n = c->nodes[(size_t)pe.node];
-        K2aVfo &k = g2a[pe.group][(size_t)pe.idx];
+    for (size_t q = 0; q < d2a.size(); ++q) {
+        Node &n = c->nodes[(size_t)n2a[q]];
+        K2aVfo &k = d2a[q];
         for (int p = 0; p < 2; ++p) {
             k.x[p] = reinterpret_cast<const float2 *>(P(n.off_stream[p]));
             k.x_next[p] = reinterpret_cast<float2 *>(P(n.off_stream[p ^ 1]));
@@ -699,9 +741,9 @@ int sdrx_finalize(sdrx_ctx *c)
         k.L = n.d.late_decimate;
         k.n_out = n.n_out;
     }
-    for (auto &pe : p2) {
-        Node &n = c->nodes[(size_t)pe.node];
-        K2Vfo &k = g2[pe.group][(size_t)pe.idx];
+    for (size_t q = 0; q < d2.size(); ++q) {
+        Node &n = c->nodes[(size_t)n2[q]];
+        K2Vfo &k = d2[q];
         const bool late = n.d.late_decimate > 0;
         for (int p = 0; p < 2; ++p) {
             k.s[p] = reinterpret_cast<const float2 *>(P(late ? n.off_z[p] : n.off_stream[p]));
@@ -716,9 +758,9 @@ int sdrx_finalize(sdrx_ctx *c)
         k.n = n.n_out;
         k.nlpf = (int)n.lpf.size();
     }
-    for (auto &pe : p3) {
-        Node &n = c->nodes[(size_t)pe.node];
-        K3Vfo &k = g3[pe.group][(size_t)pe.idx];
+    for (size_t q = 0; q < d3.size(); ++q) {
+        Node &n = c->nodes[(size_t)n3[q]];
+        K3Vfo &k = d3[q];
         for (int p = 0; p < 2; ++p)
             k.s[p] = reinterpret_cast<const float2 *>(P(n.off_stream[p])) + n.Hx;
         k.pay = reinterpret_cast<signed char *>(c->d_pay + n.pay_off);
@@ -733,12 +775,12 @@ int sdrx_finalize(sdrx_ctx *c)
     HIPCHK(c, up(off_nco_jobs, jobs.data(), sizeof(NcoInit) * jobs.size()));
     for (int lv = 0; lv < c->n_levels; ++lv)
         HIPCHK(c, up(c->l1[(size_t)lv].off_work, works[(size_t)lv].data(), sizeof(K1Work) * works[(size_t)lv].size()));
-    for (auto &kv : g2a)
-        HIPCHK(c, up(o2a[kv.first], kv.second.data(), sizeof(K2aVfo) * kv.second.size()));
-    for (auto &kv : g2)
-        HIPCHK(c, up(o2[kv.first], kv.second.data(), sizeof(K2Vfo) * kv.second.size()));
-    for (auto &kv : g3)
-        HIPCHK(c, up(o3[kv.first], kv.second.data(), sizeof(K3Vfo) * kv.second.size()));
+    HIPCHK(c, up(o2a, d2a.data(), sizeof(K2aVfo) * d2a.size()));
+    HIPCHK(c, up(ow2a, w2a.data(), sizeof(BlockWork) * w2a.size()));
+    HIPCHK(c, up(o2, d2.data(), sizeof(K2Vfo) * d2.size()));
+    HIPCHK(c, up(ow2, w2.data(), sizeof(BlockWork) * w2.size()));
+    HIPCHK(c, up(o3, d3.data(), sizeof(K3Vfo) * d3.size()));
+    HIPCHK(c, up(ow3, w3.data(), sizeof(BlockWork) * w3.size()));
     for (auto &kv : tap_offsets)
         HIPCHK(c, up(kv.second, kv.first.data(), kv.first.size() * sizeof(float)));
     HIPCHK(c, hipStreamSynchronize(c->stream)); // host vectors above go out of scope

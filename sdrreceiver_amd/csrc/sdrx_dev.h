@@ -35,6 +35,12 @@ struct K1Work {
     int c_begin, c_first_out, c_end;
 };
 
+// One block's job in the block-per-tile kernels (late decimation, demod, compress).
+struct BlockWork {
+    int vfo; // index into that kernel's descriptor array
+    int blk; // tile index within the VFO-frame
+};
+
 // ---- late decimation by L (vfo::usb_decimdemod, vfo.cpp:334-387) ------------------------------
 struct K2aVfo {
     const float2 *x[2];     // [hist Hx | data n] per parity

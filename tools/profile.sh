@@ -1,0 +1,21 @@
+#!/bin/bash
+# tools/profile.sh <tag> [bench args...] -- rocprofv3 passes of bench.py on the GPU box.
+# Writes gpurun_out/prof_<tag>/: kernel-trace stats, then separate --pmc passes (never combined
+# with tracing domains).  Copy what should be judged into profiles/.
+set -u
+TAG=${1:-run}; shift || true
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+ARGS="--steps 20 --warmup 3 --no-cpu $*"
+python3 bench.py $ARGS > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
+rocprofv3 --kernel-trace --stats -d "$OUT" -o trace --output-format csv -- python3 bench.py $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
+# counter passes: one small group per run (SQ has 8 slots, TCC 4: FETCH_SIZE costs 3, WRITE_SIZE 2)
+i=0
+for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" \
+           "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  rocprofv3 --pmc $PMC -d "$OUT" -o pmc$i --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu $* > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err" || echo "pmc pass $i failed: $PMC" >> "$OUT/errors.txt"
+done
+ls "$OUT"
