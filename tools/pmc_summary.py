@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""tools/pmc_summary.py <prof_dir> <out_json> [workload] [exact]
+
+Condense the rocprofv3 --pmc passes written by tools/profile.sh into per-kernel, per-launch numbers:
+HBM bytes (FETCH_SIZE / WRITE_SIZE are reported in KiB-ish units of 1024 B; on gfx950 FETCH_SIZE
+counts 128-byte requests as 64 bytes, so it is doubled -- MI355X_MICROARCH.md, section HBM), VALU /
+LDS / wait counters, L2 hit rate.  bench.py reads the result (profiles/current_pmc.json) for
+roofline.traffic."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+KERNEL_KEYS = {
+    "k_mix_decimate<true, 1>": "k_mix_decimate(sub)", "k_mix_decimate<false, 1>": "k_mix_decimate(sub)",
+    "k_mix_decimate<true, 0>": "k_mix_decimate(level0)", "k_mix_decimate<false, 0>": "k_mix_decimate(level0)",
+    "k_usb_demod": "k_usb_demod", "k_late_decimate": "k_late_decimate", "k_compress": "k_compress",
+    "k_ingest": "k_ingest",
+}
+
+
+def key_of(name):
+    for k, v in KERNEL_KEYS.items():
+        if k in name:
+            return v
+    return None
+
+
+def main():
+    d, out = sys.argv[1], sys.argv[2]
+    workload = sys.argv[3] if len(sys.argv) > 3 else "config3"
+    exact = (sys.argv[4] != "0") if len(sys.argv) > 4 else True
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in sorted(glob.glob(os.path.join(d, "pmc*_counter_collection.csv"))):
+        for r in csv.DictReader(open(f)):
+            k = key_of(r["Kernel_Name"])
+            if k:
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {"source": os.path.relpath(d), "workload": workload, "exact": exact, "kernels": {},
+           "note": "per-launch means; hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE correction)"}
+    for k, c in agg.items():
+        m = {n: sum(v) / len(v) for n, v in c.items()}
+        e = {"counters": {n: round(v, 1) for n, v in m.items()}}
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            e["hbm_read_bytes_per_launch"] = int(2 * m["FETCH_SIZE"] * 1024)
+            e["hbm_write_bytes_per_launch"] = int(m["WRITE_SIZE"] * 1024)
+            e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+        if "TCC_HIT_sum" in m:
+            e["l2_hit_rate"] = round(m["TCC_HIT_sum"] / max(1.0, m["TCC_HIT_sum"] + m["TCC_MISS_sum"]), 3)
+        res["kernels"][k] = e
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps({k: {x: v.get(x) for x in ("hbm_bytes_per_launch", "l2_hit_rate")} for k, v in res["kernels"].items()}))
+
+
+if __name__ == "__main__":
+    main()
