@@ -189,6 +189,80 @@ __global__ __launch_bounds__(256) void k_ingest_f32(const float4 *__restrict__ n
     tiled[tile_unit(c, r & 7, r >> 3)] = nat[p];
 }
 
+// Dongle bytes -> cf32 in tile layout: floats[b] = b - 127 (jonti/sdr.cpp:43-49,122-129;
+// sdrj.cpp:155-160).  One thread = one complex pair (4 bytes).
+__global__ __launch_bounds__(256) void k_ingest_u8(const unsigned *__restrict__ bytes4, float4 *__restrict__ tiled, int n_pairs)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pairs)
+        return;
+    const unsigned w = bytes4[p];
+    const float4 v = make_float4((float)((int)(w & 255u) - 127), (float)((int)((w >> 8) & 255u) - 127),
+                                 (float)((int)((w >> 16) & 255u) - 127), (float)((int)(w >> 24) - 127));
+    const int c = p >> 9, r = p & 511;
+    tiled[tile_unit(c, r & 7, r >> 3)] = v;
+}
+
+// The same with the DC-bias removal of sdrj::demodData (sdrj.cpp:271-286):
+//   avept = avept*(1.0f-0.000001f) + 0.000001f*curr;  curr -= avept        (per component, fp32)
+// with an accumulator that lives for the whole process (function-static there; `state` here).
+// It is a true first-order recurrence in ROUNDED fp32 arithmetic, so the bit-exact form is
+// sequential: ONE wave walks the frame in 1024-sample chunks, lanes 0 and 1 run the I and the Q
+// recurrence out of LDS (2 dependent VALU ops per sample), then all 64 lanes subtract and store the
+// chunk in tile layout.  ~10 cycles per sample: ~1.7 ms for a 384 000-sample frame -- far inside the
+// 250 ms frame period, and the only serial piece of the whole pipeline.
+__global__ __launch_bounds__(64) void k_ingest_u8_dc(const unsigned *__restrict__ bytes4, float4 *__restrict__ tiled, int n_complex,
+                                                     float *__restrict__ state)
+{
+    __shared__ __attribute__((aligned(16))) unsigned sB[kChunk / 2]; // 1024 samples = 2048 bytes
+    __shared__ __attribute__((aligned(16))) float sA[2][kChunk];     // avept after each sample, per component
+    const int lane = threadIdx.x;
+    const float keep = 1.0f - 0.000001f, k = 0.000001f;
+    float acc = lane < 2 ? state[lane] : 0.f;
+    const int nchunks = (n_complex + kChunk - 1) / kChunk;
+    for (int c = 0; c < nchunks; ++c) {
+        const int base = c * kChunk;
+        const int valid = min(kChunk, n_complex - base);
+        __syncthreads();
+        for (int i = lane; i < kChunk / 2; i += 64)
+            sB[i] = (2 * i < valid) ? bytes4[(base >> 1) + i] : 0x7f7f7f7fu;
+        __syncthreads();
+        if (lane < 2) {
+            const int sh = 8 * lane; // byte lane: I = byte 0 / 2, Q = byte 1 / 3 of each word
+            for (int i = 0; i < valid; i += 8) {
+                const uint4 w = *reinterpret_cast<const uint4 *>(sB + (i >> 1));
+                const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = (float)((int)((ws[j] >> sh) & 255u) - 127);
+                    const float x1 = (float)((int)((ws[j] >> (16 + sh)) & 255u) - 127);
+                    acc = acc * keep + k * x0;
+                    sA[lane][i + 2 * j] = acc;
+                    acc = acc * keep + k * x1;
+                    sA[lane][i + 2 * j + 1] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        // lane l owns samples 16 l .. 16 l + 15 of the chunk = 8 words of sB
+#pragma unroll
+        for (int i2 = 0; i2 < 8; ++i2) {
+            const int s0 = lane * kRun + 2 * i2;
+            const unsigned w = sB[s0 >> 1];
+            float4 v = make_float4((float)((int)(w & 255u) - 127), (float)((int)((w >> 8) & 255u) - 127),
+                                   (float)((int)((w >> 16) & 255u) - 127), (float)((int)(w >> 24) - 127));
+            v.x -= sA[0][s0];
+            v.y -= sA[1][s0];
+            v.z -= sA[0][s0 + 1];
+            v.w -= sA[1][s0 + 1];
+            if (s0 < valid)
+                tiled[tile_unit(c, i2, lane)] = v;
+        }
+    }
+    if (lane < 2)
+        state[lane] = acc;
+}
+
 // ------------------------------------------------------------------------------------ k_mix_decimate
 // Whole-wave DPP shift by one lane (GFX9 `wave_shr:1`): lane l receives src of lane l-1,
 // lane 0 keeps `old`.  Lane semantics verified on gfx950 by tools/dpp_probe.hip.

@@ -220,7 +220,7 @@ template <bool EXACT>
 int enqueue_frame(sdrx_ctx *c, const float2 *raw)
 {
     const K1Vfo *k1 = reinterpret_cast<const K1Vfo *>(c->arena + c->off_k1vfo);
-    {
+    if (raw) { // (nullptr: an ingest kernel has already filled d_raw_tiled)
         // natural-order raw frame -> tile layout (the layout every k_mix_decimate input has)
         Bracket b(c, KIND_INGEST, 0);
         const int n_pairs = c->root_frame / 2;
@@ -893,9 +893,38 @@ int sdrx_process(sdrx_ctx *c, const float *iq, int n_complex)
     return sdrx_fetch(c);
 }
 
-int sdrx_process_u8(sdrx_ctx *c, const uint8_t *, int, int)
+int sdrx_process_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correct_dc)
 {
-    return fail(c, SDRX_EUNSUPPORTED, "sdrx_process_u8: device-side byte ingest is not built yet");
+    if (!c || !bytes)
+        return SDRX_EINVAL;
+    if (!c->finalized)
+        return fail(c, SDRX_ESTATE, "sdrx_process_u8 before sdrx_finalize");
+    if (n_complex != c->root_frame)
+        return fail(c, SDRX_EINVAL, "frame of %d samples, VFOs were initialised for %d (vfo::init samplesPerBuffer)", n_complex,
+                    c->root_frame);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_raw(c, (size_t)c->root_frame);
+    if (rc)
+        return rc;
+    if (!c->d_dc_state) {
+        HIPCHK(c, hipMalloc(&c->d_dc_state, 2 * sizeof(float)));
+        HIPCHK(c, hipMemsetAsync(c->d_dc_state, 0, 2 * sizeof(float), c->stream)); // `static cpx_typef avept=0`, sdrj.cpp:279
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_raw_u8, bytes, (size_t)n_complex * 2, hipMemcpyHostToDevice, c->stream));
+    {
+        Bracket b(c, KIND_INGEST, 0);
+        const int n_pairs = n_complex / 2;
+        if (correct_dc)
+            hipLaunchKernelGGL(k_ingest_u8_dc, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(c->d_raw_u8),
+                               reinterpret_cast<float4 *>(c->d_raw_tiled), n_complex, c->d_dc_state);
+        else
+            hipLaunchKernelGGL(k_ingest_u8, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream,
+                               reinterpret_cast<const unsigned *>(c->d_raw_u8), reinterpret_cast<float4 *>(c->d_raw_tiled), n_pairs);
+    }
+    rc = c->opt_exact ? enqueue_frame<true>(c, nullptr) : enqueue_frame<false>(c, nullptr);
+    if (rc)
+        return rc;
+    return sdrx_fetch(c);
 }
 
 int sdrx_get_output(sdrx_ctx *c, int id, const void **buf, uint32_t *len, uint32_t *rate)

@@ -94,6 +94,13 @@ class Receiver:
         self.published.clear()
         self._chk(self.L.sdrx_process(self.h, iq.ctypes.data, iq.size // 2))
 
+    def process_u8(self, iq_bytes, correct_dc: bool = False) -> None:
+        """One frame of raw dongle bytes (I,Q unsigned, offset 127), LUT + optional DC-bias IIR on the
+        device (sdrj::readyRead + demodData, sdrj.cpp:149-165,271-286)."""
+        b = np.ascontiguousarray(iq_bytes, dtype=np.uint8).reshape(-1)
+        self.published.clear()
+        self._chk(self.L.sdrx_process_u8(self.h, b.ctypes.data, b.size // 2, int(bool(correct_dc))))
+
     def process_device(self, dev_ptr: int, n_complex: int) -> None:
         self._chk(self.L.sdrx_process_device(self.h, C.c_void_p(dev_ptr), int(n_complex)))
 

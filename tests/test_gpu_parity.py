@@ -275,3 +275,26 @@ def test_error_behaviour(Receiver):
         rx.process(np.zeros(8, np.float32))  # before finalize
     assert e.value.code == -2
     rx.close()
+
+
+# ------------------------------------------------------------------------------ byte ingest
+@pytest.mark.parametrize("correct_dc", [False, True])
+def test_u8_ingest_and_dc_bias_on_device(Receiver, correct_dc):
+    """sdrx_process_u8: the b-127 LUT (jonti/sdr.cpp:43-49) and the DC-bias IIR of
+    sdrj::demodData (sdrj.cpp:271-286, state persisting across frames) done on the device, against
+    the oracle's host-side restatement feeding the same chain.  Bit-exact."""
+    topo = tp.config2()
+    rx = Receiver.from_topology(topo, exact=True)
+    nodes, roots = ob.build_tree("port", topo)
+    rng = np.random.default_rng(3)
+    state = np.zeros(2, np.float32)
+    for f in range(3):
+        b = rng.integers(0, 256, 2 * topo.frame, dtype=np.uint8)
+        b[0::2] = np.clip(b[0::2].astype(int) // 8 + 130, 0, 255)  # a DC offset worth removing
+        rx.process_u8(b, correct_dc=correct_dc)
+        iq = ob.u8_to_float(b)
+        if correct_dc:
+            ob.dc_correct(iq, state)
+        ob.process_roots(roots, iq)
+        _check_exact(rx, nodes, topo, ("u8", correct_dc, f))
+    rx.close()
