@@ -299,6 +299,17 @@ __host__ __device__ constexpr int k1_lds_bytes(int d, bool need_transpose)
     return kCarryBytes + (stages > tr ? stages : tr);
 }
 
+// k_mix_decimate is ONE wave per workgroup and every LDS byte it touches is private to that wave.
+// A wave's LDS instructions execute in program order, so a write by one lane is visible to a later
+// read by another lane without any wait; all that is needed between phases is that the COMPILER
+// keeps the order.  __syncthreads() would do that too, but it also emits s_waitcnt vmcnt(0): every
+// phase boundary would drain the global loads and stores in flight (ten times per chunk).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // One half-band stage of one chunk in LDS (stages >= 2): A = [16 carry | cnt data] -> B data, or
 // the output stream when this is the last stage.
 template <bool EXACT>
@@ -306,7 +317,7 @@ __device__ __forceinline__ void hb_stage_lds(v2f *__restrict__ A, v2f *__restric
                                              bool tiled, bool last, bool emit, int cnt, int lane, bool save,
                                              float2 *__restrict__ hbsave)
 {
-    __syncthreads(); // stage input (written by the previous phase) is visible
+    wave_sync(); // stage input (written by the previous phase) is visible
     const int nout = cnt >> 1;
     for (int j = lane; j < nout; j += 64) {
         const v2f *w = A + kCarry + 2 * j - 10; // w[0..10], newest = input sample 2j of this chunk
@@ -316,14 +327,14 @@ __device__ __forceinline__ void hb_stage_lds(v2f *__restrict__ A, v2f *__restric
         else if (emit)
             gstv2(gout + (tiled ? tile_pos(gbase + j) : (size_t)(gbase + j)), y);
     }
-    __syncthreads(); // all window reads done before the carry is overwritten
+    wave_sync(); // all window reads done before the carry is overwritten
     // FIRQueueBackToFront (dsp.cpp:163-173) at the end of the FRAME: x[-k] := x[size-1-k]
     if (save && lane < kHbHist)
         gstv2(hbsave + lane, A[kCarry + cnt - 2 - lane]);
     v2f t;
     if (lane < kCarry)
         t = A[cnt + lane]; // the last 16 of [carry | data]
-    __syncthreads();
+    wave_sync();
     if (lane < kCarry)
         A[lane] = t;
 }
@@ -392,7 +403,11 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
     for (int c = W.c_begin; c < W.c_end; ++c) {
         const int base = c * kChunk;
         const int valid = min(kChunk, D.n_in - base);
+#ifndef SDRX_ABL_STORE
         const bool emit = c >= W.c_first_out;
+#else
+        const bool emit = c >= W.c_first_out && D.n_in == 12345; // ablation: never true at run time
+#endif
         const bool save = c == nchunks - 1 && W.c_end == nchunks;
         const int lv = (valid >> 4) - 1; // last lane holding real samples
         const bool active = lane <= lv;
@@ -402,7 +417,12 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
         v2f *x = ext0 + 10;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+#ifndef SDRX_ABL_LOAD
             const v4f v = gldv4(in + tile_unit(c, i, lane));
+#else
+            v4f v = {1.f * lane, 2.f, 3.f * c, 4.f * i}; // ablation: no global loads
+            asm volatile("" : "+v"(v));
+#endif
             x[2 * i] = lo2(v);
             x[2 * i + 1] = hi2(v);
         }
@@ -418,11 +438,19 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
         const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
 #pragma unroll
         for (int i = 0; i < kRun; ++i) {
+#ifndef SDRX_ABL_NCO
             o = nco_step_pk(o, rot);
+#else
+            asm volatile("" : "+v"(o)); // ablation: keep the value opaque, skip the recurrence
+#endif
             v2f m = o;
             if (i == 0 && first_ever)
                 m = gldv2(D.cp + (D.L >> 4));
+#ifndef SDRX_ABL_MIX
             x[i] = cmul(m, x[i]);
+#else
+            x[i] = x[i] + m;
+#endif
         }
 
         if (D.d == 0) {
@@ -436,11 +464,11 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
                 }
             } else {
                 // natural order wanted: transpose through LDS so the stores are coalesced
-                __syncthreads();
+                wave_sync();
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     *reinterpret_cast<v4f *>(lds + pad0(lane * kRun + 2 * i)) = cat2(x[2 * i], x[2 * i + 1]);
-                __syncthreads();
+                wave_sync();
                 if (emit) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -455,7 +483,8 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
 
         // 3. stage 0 in registers.  Halo = the previous lane's x[6,8,10,11,12,13,14,15]
         //    (one whole-wave DPP shift each); lane 0 takes the previous chunk's lane 63 from LDS.
-        __syncthreads(); // car0/car1 of the previous chunk (or the initial state) are visible
+#ifndef SDRX_ABL_CARRY
+        wave_sync(); // car0/car1 of the previous chunk (or the initial state) are visible
         {
             const v4f *c4 = reinterpret_cast<const v4f *>(car0); // broadcast reads
             const v4f q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
@@ -469,7 +498,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
             ext0[9] = shr1(hi2(q3), x[15]);  // x[-1]
             ext0[1] = ext0[3] = zero2;       // x[-9], x[-7]: never read
         }
-        __syncthreads(); // every lane holds its halo: lane 63 may now leave ITS tail for the next chunk
+        wave_sync(); // every lane holds its halo: lane 63 may now leave ITS tail for the next chunk
         if (lane == 63) {
             v4f *c4 = reinterpret_cast<v4f *>(car0);
             c4[0] = cat2(x[6], x[8]);
@@ -477,9 +506,18 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
             c4[2] = cat2(x[12], x[13]);
             c4[3] = cat2(x[14], x[15]);
         }
+#else
+        for (int q = 0; q < 10; ++q) ext0[q] = x[q]; // ablation: no LDS carry, no DPP
+#endif
         v2f ext1[10 + 8]; // ext1[10 + t] = y[t] (stage-0 outputs of this lane), ext1[0..9] halo
         v2f *y = ext1 + 10;
+#ifndef SDRX_ABL_ST0
         hb_regs<EXACT, 8>(ext0, y);
+#else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) // ablation: 1 add instead of the 11-op dot
+            y[j] = ext0[2 * j] + ext0[2 * j + 10];
+#endif
         if (save && lane == lv) // next frame's stage-0 history: x[size-1-k], k = 1..10
 #pragma unroll
             for (int k = 1; k <= kHbHist; ++k)
@@ -497,6 +535,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
             continue;
         }
 
+#ifndef SDRX_ABL_CARRY
         // 4. stage 1 in registers.  Halo y[-8,-6,-5,-4,-3,-2,-1] = previous lane's y[0,2..7],
         //    y[-10] = the lane before that one's y[6] (a second shift of the shifted y[6]).
         {
@@ -512,7 +551,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
             ext1[0] = shr1(lo2(q0), ext1[8]); // y[-10]
             ext1[1] = ext1[3] = zero2;
         }
-        __syncthreads(); // every lane has read car1
+        wave_sync(); // every lane has read car1
         if (lane == 63) {
             car1[1] = y[0]; // slot 1 (y[-8]); slot 0 comes from lane 62
             v4f *d4 = reinterpret_cast<v4f *>(car1);
@@ -522,6 +561,9 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
         }
         if (lane == 62)
             car1[0] = y[6];
+#else
+        for (int q = 0; q < 10; ++q) ext1[q] = y[q & 7];
+#endif
         if (save) { // next frame's stage-1 history: y[size1-1-k]
             if (lane == lv)
 #pragma unroll
@@ -533,7 +575,13 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
                     gstv2(hb_save + 1 * kHbHist + k - 1, y[15 - k]);
         }
         v2f z[4];
+#ifndef SDRX_ABL_ST1
         hb_regs<EXACT, 4>(ext1, z);
+#else
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            z[j] = ext1[2 * j] + ext1[2 * j + 10];
+#endif
 
         if (D.d == 2) {
             if (emit && active) {
@@ -553,6 +601,11 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
             *reinterpret_cast<v4f *>(A2) = cat2(z[0], z[1]);
             *reinterpret_cast<v4f *>(A2 + 2) = cat2(z[2], z[3]);
         }
+#ifdef SDRX_ABL_LDS
+        if (emit && lane < 32) // ablation: skip the LDS stages, write something that depends on z
+            gstv2(out + (base >> D.d) + lane, z[0] + z[1] + z[2] + z[3]);
+        continue;
+#endif
         for (int s = kRegStages; s < D.d; ++s)
             hb_stage_lds<EXACT>(lds + stage_offset(s), lds + stage_offset(s + 1), out, base >> D.d, D.out_tiled != 0, s + 1 == D.d, emit,
                                 valid >> s, lane, save, hb_save + s * kHbHist);

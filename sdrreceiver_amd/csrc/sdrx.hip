@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -551,57 +552,25 @@ int sdrx_finalize(sdrx_ctx *c)
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
             ncu = prop.multiProcessorCount;
     }
-    // Segmentation.  A work item is one wave walking `seglen` chunks (+ W warm-up chunks when it
-    // starts mid-frame).  The whole launch should be ONE resident round of equally long items:
-    // items <= slots (CUs x resident waves per CU, from the occupancy query) and the same seglen
-    // for every VFO of the level, so no CU sits idle behind a long straggler.
-    std::vector<int> level_seglen((size_t)c->n_levels, 0);
-    for (int lv = 0; lv < c->n_levels; ++lv) {
-        const int lds = k1_lds_bytes(level_maxd[(size_t)lv], false);
-        int per_cu = 0;
-        hipError_t oe = c->opt_exact
-            ? (lv == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mix_decimate<true, 0>, 64, (size_t)lds)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mix_decimate<true, 1>, 64, (size_t)lds))
-            : (lv == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mix_decimate<false, 0>, 64, (size_t)lds)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mix_decimate<false, 1>, 64, (size_t)lds));
-        if (oe != hipSuccess || per_cu <= 0)
-            per_cu = 16;
-        const long long slots = (long long)ncu * per_cu;
-        long long total = 0;
-        int max_chunks = 1, min_chunks = 1 << 30, Wmax = 0;
-        for (const Node &n : c->nodes)
-            if (n.level == lv) {
-                const int nc = (n.d.samples_per_buffer + kChunk - 1) / kChunk;
-                total += nc;
-                max_chunks = std::max(max_chunks, nc);
-                min_chunks = std::min(min_chunks, nc);
-                Wmax = std::max(Wmax, warmup_chunks(n.d.decimate_count));
-            }
-        auto items_at = [&](int seglen) {
-            long long it = 0;
-            for (const Node &n : c->nodes)
-                if (n.level == lv)
-                    it += ((n.d.samples_per_buffer + kChunk - 1) / kChunk + seglen - 1) / seglen;
-            return it;
-        };
-        int seglen;
-        if (total * 4 <= slots * std::max(4, 6 * Wmax)) {
-            // tiny level (the 2-3 main VFOs, or a small profile): latency matters, not redundancy
-            seglen = std::max(1, std::max(Wmax, (int)((total + slots - 1) / slots)));
-        } else if (total <= slots * (long long)max_chunks) {
-            seglen = std::max((int)((total + slots - 1) / slots), std::max(4, 6 * Wmax));
-            while (seglen < max_chunks && items_at(seglen) > slots)
-                ++seglen;
-        } else {
-            seglen = std::max(min_chunks, std::max(4, 6 * Wmax)); // many rounds: uniform item size, dynamic balance
-        }
-        level_seglen[(size_t)lv] = seglen;
-    }
+    // Segmentation.  A work item is one wave walking a run of chunks of one VFO-frame (+ W warm-up
+    // chunks when it starts mid-frame).  Measured on config 3 (profiles/README.md): the same NUMBER
+    // of segments for every VFO of a level, 32 work items per CU in total, in VFO
+    // creation order (the long d=5 items of the first parent first, the short d=2 items of the
+    // second parent back-filling the tail) beats one resident round of equal-length items (86 vs
+    // 91.5 us), equal-length short items (94-99 us), class-interleaved order (103 us) and
+    // segment-major order (96-102 us).
+    std::vector<int> level_nseg((size_t)c->n_levels, 1);
+    for (int lv = 0; lv < c->n_levels; ++lv) // 32 work items per CU (= the hardware's wave slots per CU)
+        level_nseg[(size_t)lv] = std::max(1, (ncu * 32 + level_count[(size_t)lv] - 1) / level_count[(size_t)lv]);
     for (int i = 0; i < N; ++i) {
         const Node &n = c->nodes[(size_t)i];
         const int nchunks = (n.d.samples_per_buffer + kChunk - 1) / kChunk;
         const int W = warmup_chunks(n.d.decimate_count);
-        int nseg = c->opt_segments > 0 ? c->opt_segments : (nchunks + level_seglen[(size_t)n.level] - 1) / level_seglen[(size_t)n.level];
+        // few VFOs in the level (the 2-3 mains): segments as short as the warm-up allows;
+        // otherwise at least 4 chunks (and 4 W) of useful work per segment
+        const bool few = (long long)level_count[(size_t)n.level] * nchunks < (long long)ncu * 16;
+        const int min_seg = few ? std::max(1, W) : std::max(4, 4 * W);
+        int nseg = c->opt_segments > 0 ? c->opt_segments : std::min(level_nseg[(size_t)n.level], std::max(1, nchunks / min_seg));
         nseg = std::max(1, std::min(nseg, nchunks / std::max(1, W)));
         for (int s = 0; s < nseg; ++s) {
             K1Work w;
@@ -614,6 +583,14 @@ int sdrx_finalize(sdrx_ctx *c)
             if (w.c_end > w.c_first_out)
                 works[(size_t)n.level].push_back(w);
         }
+    }
+    // Order of the work items inside a launch (experiment switch SDRX_ORDER, default = VFO-major,
+    // i.e. creation order; measured: spreading d=5 and d=2 items evenly through the list is 12 %
+    // SLOWER than keeping each VFO's -- and each parent's -- items together).
+    if (const char *e = getenv("SDRX_ORDER")) {
+        if (atoi(e) == 1) // segment-major: all first segments, then all second segments, ...
+            for (auto &wl : works)
+                std::stable_sort(wl.begin(), wl.end(), [](const K1Work &a, const K1Work &b) { return a.c_first_out < b.c_first_out; });
     }
     c->l1.clear();
     for (int lv = 0; lv < c->n_levels; ++lv) {
