@@ -298,3 +298,55 @@ def test_u8_ingest_and_dc_bias_on_device(Receiver, correct_dc):
         ob.process_roots(roots, iq)
         _check_exact(rx, nodes, topo, ("u8", correct_dc, f))
     rx.close()
+
+
+# ------------------------------------------------------------------------------ edge geometry
+def _edge_topology():
+    """Every decimation depth 0..8 (vfo.h:63 allows 8 stages) as parent-less USB leaves on a short
+    frame whose last chunk is partial (8704 = 8*1024 + 512), with and without the audio low-pass:
+    n_out runs from 8704 down to 34 samples per frame -- shorter than the 124-sample Hilbert
+    history, so the previous-frame history spans several frames."""
+    t = tp.Topology(fs=34816, frame=8704, name="edge")
+    for d in range(9):
+        rate = 34816 // (1 << d)
+        t.vfos.append(tp.VfoDesc(topic=f"D{d}", parent=-1, fs=34816, decimate_count=d, mixer_freq=float(1000 + 377 * d),
+                                 filter_bw=(rate // 5) if d % 2 else 0, gain=tp._g(0.05), cstyle=1, samples_per_buffer=8704))
+    t.vfos.append(tp.VfoDesc(topic="IQ", parent=-1, fs=34816, decimate_count=7, mixer_freq=-5000.0, demod_usb=False,
+                             cstyle=0, samples_per_buffer=8704))
+    return t
+
+
+@pytest.mark.parametrize("segments", [0, 1, 2])
+def test_all_decimation_depths_and_tiny_frames(Receiver, segments):
+    topo = _edge_topology()
+    rx = Receiver.from_topology(topo, exact=True, segments=segments)
+    nodes, roots = ob.build_tree("port", topo)
+    for f, iq in _frames(topo, 6, seed=21, tones=[(3000.0, 30.0), (-7000.0, 12.0)]):
+        rx.process(iq)
+        ob.process_roots(roots, iq)
+        _check_exact(rx, nodes, topo, ("edge", segments, f))
+    rx.close()
+
+
+def test_three_level_tree(Receiver):
+    """vfo::process recurses (vfo.cpp:253-264); the reference only builds two levels, the library
+    takes any depth: raw -> d=2 -> d=1 -> {d=2 USB leaf with low-pass, d=0 USB leaf, d=3 IQ leaf}."""
+    t = tp.Topology(fs=1536000, frame=384000, name="3level")
+    t.vfos.append(tp.VfoDesc(parent=-1, fs=1536000, decimate_count=2, mixer_freq=484000.0, demod_usb=False, cstyle=1,
+                             samples_per_buffer=384000))
+    t.vfos.append(tp.VfoDesc(parent=0, fs=384000, decimate_count=1, mixer_freq=-50000.0, demod_usb=False, cstyle=1,
+                             samples_per_buffer=96000))
+    t.vfos.append(tp.VfoDesc(topic="L2A", parent=1, fs=192000, decimate_count=2, mixer_freq=21000.0, filter_bw=10000,
+                             gain=tp._g(0.05), cstyle=1, samples_per_buffer=48000))
+    t.vfos.append(tp.VfoDesc(topic="L2B", parent=1, fs=192000, decimate_count=0, mixer_freq=-33000.0, gain=tp._g(0.02),
+                             cstyle=1, samples_per_buffer=48000))
+    t.vfos.append(tp.VfoDesc(topic="L2C", parent=1, fs=192000, decimate_count=3, mixer_freq=5000.0, demod_usb=False,
+                             cstyle=1, scalecomp=4, samples_per_buffer=48000))
+    rx = Receiver.from_topology(t, exact=True)
+    nodes, roots = ob.build_tree("port", t)
+    for f, iq in _frames(t, 3, seed=8, tones=[(-380000.0, 20.0)]):
+        rx.process(iq)
+        ob.process_roots(roots, iq)
+        _check_exact(rx, nodes, t, ("3level", f))
+    assert [p[0] for p in rx.published] == [b"L2A\0\0", b"L2B\0\0", b"L2C\0\0"]
+    rx.close()
