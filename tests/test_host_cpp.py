@@ -1,0 +1,127 @@
+"""The C++ host layer (host/sdrx_host.hpp: the reference's vfo / sdrj interface and the INI front
+door of mainwindow.cpp:27-233, Qt-free, over the C ABI), driven through host/sdrx_demo."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import REFERENCE_ROOT
+from sdrreceiver_amd import synth, topology as tp
+from test_topology import INI_25E_LIKE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "host", "sdrx_demo")
+
+INI_54W_LIKE = """
+sample_rate=1920000
+center_frequency=1545939000
+zmq_address=tcp://*:6004
+[main_vfos]
+size=2
+1\\frequency=1545120000
+1\\out_rate=240000
+2\\frequency=1546120000
+2\\out_rate=240000
+[vfos]
+size=3
+1\\frequency=1545014429
+1\\gain=4
+1\\data_rate=600
+1\\topic=VFO41
+2\\frequency=1546045422
+2\\gain=4
+2\\data_rate=10500
+2\\topic=VFO51
+3\\frequency=1546061717
+3\\gain=4
+3\\data_rate=10500
+3\\filter_bandwidth=10000
+3\\topic=VFO52
+"""
+
+
+def _build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")], stdout=subprocess.DEVNULL)
+
+
+def _dump(ini_text, tmp_path):
+    _build()
+    p = tmp_path / "profile.ini"
+    p.write_text(ini_text)
+    out = subprocess.check_output([DEMO, str(p), "--dump"], text=True)
+    return [json.loads(l) for l in out.splitlines()]
+
+
+def _check_dump(rows, topo):
+    head, rest = rows[0], rows[1:]
+    assert (head["fs"], head["frame"], head["bufsplit"], bool(head["correct_dc"])) == (topo.fs, topo.frame, topo.bufsplit, topo.correct_dc)
+    mains = [v for v in topo.vfos if v.parent < 0]
+    subs = [v for v in topo.vfos if v.parent >= 0]
+    assert head["n"] == len(topo.vfos)
+    for r, v in zip(rest[:len(mains)], mains):
+        assert (r["fs"], r["d"], r["mixer"], bool(r["usb"]), r["spb"], r["scalecomp"]) == \
+            (v.fs, v.decimate_count, v.mixer_freq, v.demod_usb, v.samples_per_buffer, v.scalecomp)
+    # the dump lists subs grouped by main (VFOsub[i]); within a main the INI order is kept
+    got = {(r["sub_of"], r["topic"]): r for r in rest[len(mains):]}
+    assert len(got) == len(subs)
+    for v in subs:
+        r = got[(v.parent, v.topic)]
+        assert (r["fs"], r["d"], r["late"], r["mixer"], r["bw"], r["spb"]) == \
+            (v.fs, v.decimate_count, v.late_decimate, v.mixer_freq, v.filter_bw, v.samples_per_buffer)
+        assert np.float32(r["gain"]) == np.float32(v.gain)
+
+
+@pytest.mark.parametrize("ini", [INI_25E_LIKE, INI_54W_LIKE])
+def test_cpp_ini_front_door_matches_python_rules(ini, tmp_path):
+    _check_dump(_dump(ini, tmp_path), tp.topology_from_ini(ini))
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_ROOT), reason="needs the reference's sample INIs")
+def test_cpp_ini_front_door_on_shipped_profiles(tmp_path):
+    d = os.path.join(REFERENCE_ROOT, "sample_ini")
+    for name in sorted(os.listdir(d)):
+        text = open(os.path.join(d, name), encoding="utf-8", errors="replace").read()
+        _check_dump(_dump(text, tmp_path), tp.topology_from_ini(text))
+
+
+def test_cpp_missing_profile_is_an_error(tmp_path):
+    _build()
+    r = subprocess.run([DEMO, str(tmp_path / "nope.ini"), "--dump"], capture_output=True, text=True)
+    assert r.returncode == 1 and "doesn't exist" in r.stderr
+
+
+def _fnv1a(b: bytes) -> int:
+    h = 1469598103934665603
+    for x in b:
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("u8", [False, True])
+def test_cpp_host_end_to_end(u8, tmp_path):
+    """INI -> vfo setters -> sdrj::demodData (host float path with host-side DC correction, or the
+    byte path with LUT + DC on the device) -> publish hook, against the Python host path with the
+    oracle's DC correction: same messages, same order, same bytes."""
+    from oracle import binding as ob
+    from sdrreceiver_amd.receiver import Receiver
+    _build()
+    p = tmp_path / "profile.ini"
+    p.write_text(INI_25E_LIKE)
+    out = subprocess.check_output([DEMO, str(p), "--frames", "2"] + (["--u8"] if u8 else []), text=True)
+    got = [l.split() for l in out.splitlines()]
+    topo = tp.topology_from_ini(INI_25E_LIKE)
+    rx = Receiver.from_topology(topo)
+    lcg = synth.Lcg(1)
+    state = np.zeros(2, np.float32)
+    want = []
+    for f in range(2):
+        iq = synth.lcg_frame(topo.frame, lcg)
+        ob.dc_correct(iq, state)  # correct_dc_bias=1 in the profile
+        rx.process(iq)
+        for topic, rate, payload in rx.published:
+            want.append([str(f), topic.rstrip(b"\0").decode(), str(rate), str(len(payload)), f"{_fnv1a(payload):016x}"])
+    rx.close()
+    assert got == want
