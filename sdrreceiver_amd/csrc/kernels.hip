@@ -74,6 +74,8 @@ __device__ __forceinline__ v2f cmul(v2f a, v2f b)
 }
 __device__ __forceinline__ v2f gldv2(const float2 *p) { return *(const SDRX_AS1 v2f *)p; }
 __device__ __forceinline__ v4f gldv4(const float4 *p) { return *(const SDRX_AS1 v4f *)p; }
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4u gldv4u(const v4u *p) { return *(const SDRX_AS1 v4u *)p; }
 __device__ __forceinline__ void gstv2(float2 *p, v2f v) { *(SDRX_AS1 v2f *)p = v; }
 __device__ __forceinline__ void gstv4(float4 *p, v4f v) { *(SDRX_AS1 v4f *)p = v; }
 
@@ -361,7 +363,7 @@ __device__ __forceinline__ constexpr int halo_k(int q) { return q == 0 ? 10 : q 
 #endif
 template <bool EXACT, int LEVEL>
 __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1Vfo *__restrict__ vfos, const K1Work *__restrict__ work,
-                                                     unsigned long long frame_no)
+                                                     unsigned long long frame_no, const void *__restrict__ raw, int raw_mode)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     v2f *car0 = reinterpret_cast<v2f *>(smem);             // [8]
@@ -415,16 +417,46 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
         // 1. this lane's run of 16 consecutive samples: 8 coalesced 16-byte loads
         v2f ext0[10 + kRun]; // ext0[10 + t] = x[t]; ext0[0..9] = halo x[-10..-1]
         v2f *x = ext0 + 10;
+        if (LEVEL == 0 && raw_mode == kRawF32) {
+            // the caller's frame as it is (natural order): each lane reads its own 128 contiguous
+            // bytes.  Uncoalesced across the wave, but a level of 2-3 main VFOs is latency bound
+            // and this saves the layout pass over the raw frame.
+            const float4 *nat = reinterpret_cast<const float4 *>(raw) + (size_t)c * 512 + lane * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 8; ++i) {
+                const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+                const v4f v = active ? gldv4(nat + i) : z4;
+                x[2 * i] = lo2(v);
+                x[2 * i + 1] = hi2(v);
+            }
+        } else if (LEVEL == 0 && raw_mode == kRawU8) {
+            // dongle bytes: floats[b] = b - 127 (jonti/sdr.cpp:43-49), 32 bytes per lane
+            const v4u *nat = reinterpret_cast<const v4u *>(raw) + (size_t)c * 128 + lane * 2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const v4u z4 = {0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu}; // 127 -> 0.0f
+                const v4u q = active ? gldv4u(nat + h) : z4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned w = q[k];
+                    const v2f a = {(float)((int)(w & 255u) - 127), (float)((int)((w >> 8) & 255u) - 127)};
+                    const v2f b = {(float)((int)((w >> 16) & 255u) - 127), (float)((int)(w >> 24) - 127)};
+                    x[8 * h + 2 * k] = a;
+                    x[8 * h + 2 * k + 1] = b;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
 #ifndef SDRX_ABL_LOAD
-            const v4f v = gldv4(in + tile_unit(c, i, lane));
+                const v4f v = gldv4(in + tile_unit(c, i, lane));
 #else
-            v4f v = {1.f * lane, 2.f, 3.f * c, 4.f * i}; // ablation: no global loads
-            asm volatile("" : "+v"(v));
+                v4f v = {1.f * lane, 2.f, 3.f * c, 4.f * i}; // ablation: no global loads
+                asm volatile("" : "+v"(v));
 #endif
-            x[2 * i] = lo2(v);
-            x[2 * i + 1] = hi2(v);
+                x[2 * i] = lo2(v);
+                x[2 * i + 1] = hi2(v);
+            }
         }
 
         // 2. NCO: regenerate table[idx .. idx+16) from the checkpoint before it, and mix
@@ -700,7 +732,10 @@ constexpr int kDemodTile = 1024;
 constexpr int kPlaneLen = (kDemodTile + kMaxFir + kHilbert + 1) / 2 + 8;
 
 template <bool EXACT>
-__global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfos, const BlockWork *__restrict__ work,
+#ifndef SDRX_DEMOD_WAVES
+#define SDRX_DEMOD_WAVES 1
+#endif
+__global__ __launch_bounds__(256, SDRX_DEMOD_WAVES) void k_usb_demod(const K2Vfo *__restrict__ vfos, const BlockWork *__restrict__ work,
                                                    unsigned long long frame_no)
 {
     __shared__ __attribute__((aligned(16))) float sP0[kPlaneLen + 4]; // even offsets from `lo`, stored shifted by +3

@@ -101,6 +101,7 @@ struct sdrx_ctx {
     size_t pay_bytes = 0;
     float2 *d_raw = nullptr;       // staging for host-fed frames (natural order)
     float2 *d_raw_tiled = nullptr; // the raw frame in tile layout: input of the parent-less VFOs
+    bool root_direct = false;      // level 0 reads the caller's natural-order frame itself (few VFOs)
     unsigned char *d_raw_u8 = nullptr;
     float *d_dc_state = nullptr;
     size_t raw_cap = 0;
@@ -218,23 +219,31 @@ struct Bracket { // RAII: event pair around one launch when timing is on
 };
 
 template <bool EXACT>
-int enqueue_frame(sdrx_ctx *c, const float2 *raw)
+int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode)
 {
     const K1Vfo *k1 = reinterpret_cast<const K1Vfo *>(c->arena + c->off_k1vfo);
-    if (raw) { // (nullptr: an ingest kernel has already filled d_raw_tiled)
-        // natural-order raw frame -> tile layout (the layout every k_mix_decimate input has)
+    // A few parent-less VFOs (the reference's 2-3 mains) read the caller's frame as it is; a wide
+    // level 0 (the flat workloads) is bandwidth bound and wants coalesced reads: one layout pass
+    // natural order -> tile layout first.
+    if (raw_mode != kRawTiled && !c->root_direct) {
         Bracket b(c, KIND_INGEST, 0);
         const int n_pairs = c->root_frame / 2;
-        hipLaunchKernelGGL(k_ingest_f32, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream,
-                           reinterpret_cast<const float4 *>(raw), reinterpret_cast<float4 *>(c->d_raw_tiled), n_pairs);
+        if (raw_mode == kRawF32)
+            hipLaunchKernelGGL(k_ingest_f32, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream,
+                               reinterpret_cast<const float4 *>(raw), reinterpret_cast<float4 *>(c->d_raw_tiled), n_pairs);
+        else
+            hipLaunchKernelGGL(k_ingest_u8, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream,
+                               reinterpret_cast<const unsigned *>(raw), reinterpret_cast<float4 *>(c->d_raw_tiled), n_pairs);
+        raw_mode = kRawTiled;
     }
     for (const Launch1 &L : c->l1) {
         Bracket b(c, L.kind, L.alg_bytes);
         const K1Work *w = reinterpret_cast<const K1Work *>(c->arena + L.off_work);
         if (L.level == 0)
-            hipLaunchKernelGGL((k_mix_decimate<EXACT, 0>), dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1, w, c->frame_no);
+            hipLaunchKernelGGL((k_mix_decimate<EXACT, 0>), dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1, w, c->frame_no, raw, raw_mode);
         else
-            hipLaunchKernelGGL((k_mix_decimate<EXACT, 1>), dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1, w, c->frame_no);
+            hipLaunchKernelGGL((k_mix_decimate<EXACT, 1>), dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1, w, c->frame_no,
+                               (const void *)nullptr, kRawTiled);
     }
     for (const LaunchB &L : c->lb) {
         Bracket b(c, L.kind, L.alg_bytes);
@@ -676,6 +685,7 @@ int sdrx_finalize(sdrx_ctx *c)
         const size_t raw_tiles = align_up((size_t)c->root_frame, kChunk);
         HIPCHK(c, hipMalloc(&c->d_raw_tiled, raw_tiles * sizeof(float2)));
         HIPCHK(c, hipMemsetAsync(c->d_raw_tiled, 0, raw_tiles * sizeof(float2), c->stream));
+        c->root_direct = level_count[0] <= 4 && !getenv("SDRX_NO_ROOT_DIRECT"); // the reference allows 3 mains (mainwindow.h:82)
     }
     auto P = [&](size_t off) { return c->arena + off; };
     std::vector<K1Vfo> k1((size_t)N);
@@ -809,8 +819,7 @@ int sdrx_process_device(sdrx_ctx *c, const void *dev_iq, int n_complex)
     if (!dev_iq)
         return fail(c, SDRX_EINVAL, "null frame pointer");
     HIPCHK(c, hipSetDevice(c->device));
-    const float2 *raw = reinterpret_cast<const float2 *>(dev_iq);
-    return c->opt_exact ? enqueue_frame<true>(c, raw) : enqueue_frame<false>(c, raw);
+    return c->opt_exact ? enqueue_frame<true>(c, dev_iq, kRawF32) : enqueue_frame<false>(c, dev_iq, kRawF32);
 }
 
 int sdrx_sync(sdrx_ctx *c)
@@ -888,17 +897,14 @@ int sdrx_process_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correc
         HIPCHK(c, hipMemsetAsync(c->d_dc_state, 0, 2 * sizeof(float), c->stream)); // `static cpx_typef avept=0`, sdrj.cpp:279
     }
     HIPCHK(c, hipMemcpyAsync(c->d_raw_u8, bytes, (size_t)n_complex * 2, hipMemcpyHostToDevice, c->stream));
-    {
+    int mode = kRawU8;
+    if (correct_dc) {
         Bracket b(c, KIND_INGEST, 0);
-        const int n_pairs = n_complex / 2;
-        if (correct_dc)
-            hipLaunchKernelGGL(k_ingest_u8_dc, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(c->d_raw_u8),
-                               reinterpret_cast<float4 *>(c->d_raw_tiled), n_complex, c->d_dc_state);
-        else
-            hipLaunchKernelGGL(k_ingest_u8, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream,
-                               reinterpret_cast<const unsigned *>(c->d_raw_u8), reinterpret_cast<float4 *>(c->d_raw_tiled), n_pairs);
+        hipLaunchKernelGGL(k_ingest_u8_dc, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(c->d_raw_u8),
+                           reinterpret_cast<float4 *>(c->d_raw_tiled), n_complex, c->d_dc_state);
+        mode = kRawTiled;
     }
-    rc = c->opt_exact ? enqueue_frame<true>(c, nullptr) : enqueue_frame<false>(c, nullptr);
+    rc = c->opt_exact ? enqueue_frame<true>(c, c->d_raw_u8, mode) : enqueue_frame<false>(c, c->d_raw_u8, mode);
     if (rc)
         return rc;
     return sdrx_fetch(c);

@@ -14,6 +14,10 @@ constexpr int kHilbert = 125;       // vfo.cpp:137
 constexpr int kHilbertNz = 62;      // non-zero Hilbert taps (odd indices 1..123)
 constexpr int kDelay = 62;          // vfo.cpp:136
 constexpr int kMaxFir = 256;        // longest low-pass the demod kernels stage in LDS
+// where the parent-less VFOs of a launch read the raw frame from
+constexpr int kRawTiled = 0;        // the context's tile-layout copy (an ingest kernel wrote it)
+constexpr int kRawF32 = 1;          // the caller's cf32 frame, natural order
+constexpr int kRawU8 = 2;           // the dongle's interleaved bytes, natural order
 
 // ---- mix + half-band cascade (one per VFO) ---------------------------------------------------
 struct K1Vfo {
