@@ -81,7 +81,14 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
  *            0: FMA and tree-order dot products; within 1e-6 relative of the reference.
  *   "keep_prequant" 1: also keep the pre-quantisation float `usb*gain*32768` per leaf
  *            (parity tests; sdrx_get_prequant).   default 0
- *   "segments" n: force n time-segments per VFO-frame in the decimation kernel (0 = auto). */
+ *   "segments" n: force n time-segments per VFO-frame in the decimation kernel (0 = auto).
+ *   "dc_blocked_scan" 0|1 (default 0): how sdrx_process_u8 removes the DC bias.  0 = the
+ *                 reference's sequentially rounded fp32 recurrence, bit for bit (one wave,
+ *                 ~1.7 ms per 384 000-sample frame).  1 = the same linear filter as a blocked
+ *                 parallel scan (~15 us): the true IIR response.  The reference's recurrence
+ *                 wanders around that by up to ~3e-3 of the DC offset (its rounding errors are
+ *                 correlated from step to step), so 1 is NOT within the 1e-5 parity tolerance
+ *                 of the reference unless the offset is well below 1 LSB. */
 int sdrx_set_option(sdrx_ctx *ctx, const char *name, int value);
 /* All of vfo::init for every node: NCO tables (oscillator.cpp:4-32), low-pass designs
  * (firfilter.cpp:64-119), Hilbert taps (dsp.cpp:184-217), zeroed filter state, buffers.

@@ -265,6 +265,114 @@ __global__ __launch_bounds__(64) void k_ingest_u8_dc(const unsigned *__restrict_
         state[lane] = acc;
 }
 
+// The fast-arithmetic form of the same DC-bias removal (option "exact" = 0): the recurrence is
+// linear, a_t = A a_{t-1} + B x_t, so it is evaluated as a blocked scan -- per 1024-sample chunk
+// one wave runs 16 sequential steps per lane from zero, combines the 64 lane totals with a
+// log-step scan of affine maps, and adds the carry-in  A^(16 l + i + 1) * (state before the chunk).
+// k_dc_block_sums leaves each chunk's zero-state response; k_ingest_u8_dc_fast folds the responses
+// of all earlier chunks into its own carry-in (<= 375 terms, powers of A^1024 from a host table)
+// and writes the corrected chunk in tile layout.  Chunk-level sums are kept in double; against the
+// reference's sequentially ROUNDED fp32 recurrence the estimate differs by ~1e-5 of the DC offset
+// itself (a random walk of half-ulp roundings over the filter's 1e6-sample memory), far below 1e-5
+// of the signal.  dctab: [0..16] = A^k, [32..95] = A^(16 l), [96 + k] = A^(1024 k).
+struct DcLocal {
+    float ai[kRun], aq[kRun]; // zero-state response at each of the lane's 16 samples
+    float xi[kRun], xq[kRun];
+};
+__device__ __forceinline__ void dc_local(const unsigned *__restrict__ bytes4, int base, int valid, int lane, DcLocal &L)
+{
+    const float keep = 1.0f - 0.000001f, k = 0.000001f;
+    float ai = 0.f, aq = 0.f;
+#pragma unroll
+    for (int i2 = 0; i2 < 8; ++i2) {
+        const int s0 = lane * kRun + 2 * i2;
+        const unsigned w = s0 < valid ? bytes4[((base + s0) >> 1)] : 0x7f7f7f7fu;
+        const float x[4] = {(float)((int)(w & 255u) - 127), (float)((int)((w >> 8) & 255u) - 127), (float)((int)((w >> 16) & 255u) - 127),
+                            (float)((int)(w >> 24) - 127)};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            ai = fmaf(ai, keep, k * x[2 * h]);
+            aq = fmaf(aq, keep, k * x[2 * h + 1]);
+            L.ai[2 * i2 + h] = ai, L.aq[2 * i2 + h] = aq;
+            L.xi[2 * i2 + h] = x[2 * h], L.xq[2 * i2 + h] = x[2 * h + 1];
+        }
+    }
+}
+// inclusive scan over the lanes of S_l = T_l + A16 * S_{l-1}
+__device__ __forceinline__ void dc_wave_scan(double &si, double &sq, const double *__restrict__ dctab, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double m = dctab[32 + d]; // A^(16 d)
+        const double ti = __shfl_up(si, d), tq = __shfl_up(sq, d);
+        if (lane >= d) {
+            si = fma(m, ti, si);
+            sq = fma(m, tq, sq);
+        }
+    }
+}
+__global__ __launch_bounds__(64) void k_dc_block_sums(const unsigned *__restrict__ bytes4, int n_complex, const double *__restrict__ dctab,
+                                                      double2 *__restrict__ sums)
+{
+    const int c = blockIdx.x, lane = threadIdx.x, base = c * kChunk;
+    DcLocal L;
+    dc_local(bytes4, base, min(kChunk, n_complex - base), lane, L);
+    double si = L.ai[kRun - 1], sq = L.aq[kRun - 1];
+    dc_wave_scan(si, sq, dctab, lane);
+    if (lane == 63)
+        sums[c] = make_double2(si, sq);
+}
+__global__ __launch_bounds__(64) void k_ingest_u8_dc_fast(const unsigned *__restrict__ bytes4, float4 *__restrict__ tiled, int n_complex,
+                                                          const float *__restrict__ state_in, float *__restrict__ state_out,
+                                                          const double *__restrict__ dctab, const double2 *__restrict__ sums)
+{
+    const int c = blockIdx.x, lane = threadIdx.x, base = c * kChunk;
+    const int valid = min(kChunk, n_complex - base);
+    // carry-in of the chunk: the state before the frame and every earlier chunk's response
+    double ci = 0.0, cq = 0.0;
+    for (int j = lane; j < c; j += 64) {
+        const double m = dctab[96 + (c - 1 - j)];
+        const double2 b = sums[j];
+        ci = fma(m, b.x, ci);
+        cq = fma(m, b.y, cq);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        ci += __shfl_xor(ci, d);
+        cq += __shfl_xor(cq, d);
+    }
+    ci = fma(dctab[96 + c], (double)state_in[0], ci);
+    cq = fma(dctab[96 + c], (double)state_in[1], cq);
+    DcLocal L;
+    dc_local(bytes4, base, valid, lane, L);
+    double si = L.ai[kRun - 1], sq = L.aq[kRun - 1];
+    dc_wave_scan(si, sq, dctab, lane);
+    double pi = __shfl_up(si, 1), pq = __shfl_up(sq, 1); // S_{l-1}
+    if (lane == 0)
+        pi = 0.0, pq = 0.0;
+    const double inc_i = fma(dctab[32 + lane], ci, pi), inc_q = fma(dctab[32 + lane], cq, pq); // state before this lane's run
+    float ai_last = 0.f, aq_last = 0.f;
+#pragma unroll
+    for (int i2 = 0; i2 < 8; ++i2) {
+        float y[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * i2 + h;
+            const float ai = (float)fma(dctab[i + 1], inc_i, (double)L.ai[i]);
+            const float aq = (float)fma(dctab[i + 1], inc_q, (double)L.aq[i]);
+            y[2 * h] = L.xi[i] - ai;
+            y[2 * h + 1] = L.xq[i] - aq;
+            ai_last = ai, aq_last = aq;
+        }
+        if (lane * kRun + 2 * i2 < valid)
+            tiled[tile_unit(c, i2, lane)] = make_float4(y[0], y[1], y[2], y[3]);
+    }
+    if (base + valid == n_complex && lane == (valid >> 4) - 1) { // the frame's last sample (frames are multiples of 16)
+        state_out[0] = ai_last;
+        state_out[1] = aq_last;
+    }
+}
+
 // ------------------------------------------------------------------------------------ k_mix_decimate
 // Whole-wave DPP shift by one lane (GFX9 `wave_shr:1`): lane l receives src of lane l-1,
 // lane 0 keeps `old`.  Lane semantics verified on gfx950 by tools/dpp_probe.hip.

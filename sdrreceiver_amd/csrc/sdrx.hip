@@ -90,7 +90,7 @@ struct sdrx_ctx {
     std::string err;
     std::vector<Node> nodes;
     bool finalized = false;
-    int opt_exact = 1, opt_prequant = 0, opt_segments = 0;
+    int opt_exact = 1, opt_prequant = 0, opt_segments = 0, opt_dc_blocked = 0;
     sdrx_publish_fn cb = nullptr;
     void *cb_user = nullptr;
 
@@ -103,7 +103,10 @@ struct sdrx_ctx {
     float2 *d_raw_tiled = nullptr; // the raw frame in tile layout: input of the parent-less VFOs
     bool root_direct = false;      // level 0 reads the caller's natural-order frame itself (few VFOs)
     unsigned char *d_raw_u8 = nullptr;
-    float *d_dc_state = nullptr;
+    float *d_dc_state = nullptr;   // DC-bias accumulator (exact: [2]; fast: [parity][2])
+    double *d_dc_tab = nullptr;    // fast DC scan: powers of the decay + per-chunk sums behind them
+    unsigned long long dc_frames = 0; // frames the fast scan has run on (its state ping-pongs)
+    size_t dc_tab_sums = 0;        // offset (in doubles) of the double2 sums[] inside d_dc_tab
     size_t raw_cap = 0;
     int root_frame = 0; // samples_per_buffer of the parent-less VFOs
     size_t off_k1vfo = 0;
@@ -342,6 +345,8 @@ int sdrx_destroy(sdrx_ctx *c)
         (void)hipFree(c->d_raw_tiled);
     if (c->d_dc_state)
         (void)hipFree(c->d_dc_state);
+    if (c->d_dc_tab)
+        (void)hipFree(c->d_dc_tab);
     if (c->own_stream)
         (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -360,6 +365,8 @@ int sdrx_set_option(sdrx_ctx *c, const char *name, int value)
         c->opt_prequant = value != 0;
     else if (!strcmp(name, "segments"))
         c->opt_segments = value < 0 ? 0 : value;
+    else if (!strcmp(name, "dc_blocked_scan"))
+        c->opt_dc_blocked = value != 0;
     else
         return fail(c, SDRX_EINVAL, "unknown option '%s'", name);
     return SDRX_OK;
@@ -893,15 +900,40 @@ int sdrx_process_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correc
     if (rc)
         return rc;
     if (!c->d_dc_state) {
-        HIPCHK(c, hipMalloc(&c->d_dc_state, 2 * sizeof(float)));
-        HIPCHK(c, hipMemsetAsync(c->d_dc_state, 0, 2 * sizeof(float), c->stream)); // `static cpx_typef avept=0`, sdrj.cpp:279
+        HIPCHK(c, hipMalloc(&c->d_dc_state, 4 * sizeof(float)));
+        HIPCHK(c, hipMemsetAsync(c->d_dc_state, 0, 4 * sizeof(float), c->stream)); // `static cpx_typef avept=0`, sdrj.cpp:279
     }
     HIPCHK(c, hipMemcpyAsync(c->d_raw_u8, bytes, (size_t)n_complex * 2, hipMemcpyHostToDevice, c->stream));
     int mode = kRawU8;
-    if (correct_dc) {
+    const int nchunks = (n_complex + kChunk - 1) / kChunk;
+    if (correct_dc && c->opt_dc_blocked && !c->d_dc_tab) {
+        // powers of the decay A = (float)(1 - 1e-6): [0..16] A^k, [32..95] A^(16 l), [96 + k] A^(1024 k)
+        const double A = (double)(1.0f - 0.000001f);
+        std::vector<double> tab(96 + (size_t)nchunks + 1 + 2 * (size_t)nchunks + 2, 0.0);
+        for (int k = 0; k <= 16; ++k)
+            tab[(size_t)k] = std::pow(A, k);
+        for (int l = 0; l < 64; ++l)
+            tab[32 + (size_t)l] = std::pow(A, 16.0 * l);
+        for (int k = 0; k <= nchunks; ++k)
+            tab[96 + (size_t)k] = std::pow(A, 1024.0 * k);
+        c->dc_tab_sums = (96 + (size_t)nchunks + 1 + 1) & ~(size_t)1; // 16-byte aligned double2[]
+        HIPCHK(c, hipMalloc(&c->d_dc_tab, tab.size() * sizeof(double)));
+        HIPCHK(c, hipMemcpy(c->d_dc_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (correct_dc && !c->opt_dc_blocked) {
         Bracket b(c, KIND_INGEST, 0);
         hipLaunchKernelGGL(k_ingest_u8_dc, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(c->d_raw_u8),
                            reinterpret_cast<float4 *>(c->d_raw_tiled), n_complex, c->d_dc_state);
+        mode = kRawTiled;
+    } else if (correct_dc) {
+        Bracket b(c, KIND_INGEST, 0);
+        const int par = (int)(c->dc_frames++ & 1ull);
+        double2 *sums = reinterpret_cast<double2 *>(c->d_dc_tab + c->dc_tab_sums);
+        hipLaunchKernelGGL(k_dc_block_sums, dim3(nchunks), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(c->d_raw_u8), n_complex,
+                           c->d_dc_tab, sums);
+        hipLaunchKernelGGL(k_ingest_u8_dc_fast, dim3(nchunks), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(c->d_raw_u8),
+                           reinterpret_cast<float4 *>(c->d_raw_tiled), n_complex, c->d_dc_state + 2 * par, c->d_dc_state + 2 * (par ^ 1),
+                           c->d_dc_tab, sums);
         mode = kRawTiled;
     }
     rc = c->opt_exact ? enqueue_frame<true>(c, c->d_raw_u8, mode) : enqueue_frame<false>(c, c->d_raw_u8, mode);

@@ -29,7 +29,8 @@ class SdrxError(RuntimeError):
 class Receiver:
     """One libsdrx context: a VFO tree on one GPU."""
 
-    def __init__(self, device: int = 0, exact: bool = True, keep_prequant: bool = False, segments: int = 0):
+    def __init__(self, device: int = 0, exact: bool = True, keep_prequant: bool = False, segments: int = 0,
+                 dc_blocked_scan: bool = False):
         self.L = _lib.lib()
         h = C.c_void_p()
         rc = self.L.sdrx_create(C.byref(h), int(device))
@@ -43,6 +44,7 @@ class Receiver:
         self._chk(self.L.sdrx_set_option(self.h, b"exact", int(bool(exact))))
         self._chk(self.L.sdrx_set_option(self.h, b"keep_prequant", int(bool(keep_prequant))))
         self._chk(self.L.sdrx_set_option(self.h, b"segments", int(segments)))
+        self._chk(self.L.sdrx_set_option(self.h, b"dc_blocked_scan", int(bool(dc_blocked_scan))))
         self.finalized = False
 
     # -- plumbing -----------------------------------------------------------------

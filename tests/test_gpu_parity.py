@@ -234,6 +234,50 @@ def test_full_size_properties_config3(Receiver):
     rx.close()
 
 
+def test_u8_dc_bias_blocked_scan_option(Receiver):
+    """Option dc_blocked_scan=1: the DC-bias IIR as a blocked parallel scan instead
+    of the sequential rounded recurrence.  The scan evaluates the TRUE linear filter: fed through
+    the oracle chain, the float64 IIR response reproduces the GPU result to the usual tolerance.
+    The reference's fp32 recurrence itself wanders around the true response (its rounding errors
+    are correlated from step to step: up to 8e-3 here at a 3-LSB offset), which is why the option
+    is off by default; the deviation is measured and bounded here.  The scan must also be >= 15x
+    faster than the exact one-wave recurrence (~1.7 ms per frame)."""
+    import scipy.signal as sg
+    topo = tp.config2()
+    rx = Receiver.from_topology(topo, exact=True, keep_prequant=True, dc_blocked_scan=True)
+    nodes, roots = ob.build_tree("port", topo)          # fed with the true IIR response
+    rnodes, rroots = ob.build_tree("port", topo)        # fed with the reference's recurrence
+    rng = np.random.default_rng(5)
+    A = float(np.float32(1.0) - np.float32(0.000001))
+    B = float(np.float32(0.000001))
+    z = [np.zeros(1), np.zeros(1)]
+    state = np.zeros(2, np.float32)
+    rx.enable_kernel_timing(True)
+    worst = 0.0
+    for f in range(6):
+        b = rng.integers(0, 256, 2 * topo.frame, dtype=np.uint8)
+        b[0::2] = np.clip(b[0::2].astype(int) + 3, 0, 255)
+        b[1::2] = np.clip(b[1::2].astype(int) - 2, 0, 255)
+        rx.process_u8(b, correct_dc=True)
+        x = ob.u8_to_float(b)
+        iq = x.copy()
+        for comp in (0, 1):
+            a, z[comp] = sg.lfilter([B], [1.0, -A], x[comp::2].astype(np.float64), zi=z[comp])
+            iq[comp::2] = x[comp::2] - a.astype(np.float32)
+        ob.process_roots(roots, iq)
+        _check_tolerance(rx, nodes, topo, ("u8-blocked-dc", f))
+        ref = x.copy()
+        ob.dc_correct(ref, state)
+        ob.process_roots(rroots, ref)
+        for i in (0, 1):
+            want = rnodes[i].stream()
+            worst = max(worst, float(np.abs(rx.stream(i) - want).max() / np.abs(want).max()))
+    kt = rx.kernel_times()
+    rx.close()
+    assert 1e-6 < worst < 2e-4, worst  # the reference's own wander, relative to the signal
+    assert kt["k_ingest"]["ms"] / kt["k_ingest"]["launches"] < 0.1, kt["k_ingest"]
+
+
 # ------------------------------------------------------------------------------ reference-style API
 def test_reference_named_interface(Receiver):
     """The same chain driven through the vfo / sdrj mirror classes (vfo.h:16-49, sdrj.h)."""
