@@ -819,6 +819,131 @@ __global__ __launch_bounds__(256) void k_late_decimate(const K2aVfo *__restrict_
     gst2(zout + k, make_float2(ar, ai));
 }
 
+// The same for L in {5,6} (all the reference configures, mainwindow.cpp:196-216) and Nd <= 96: ONE
+// wave per 64 R outputs, R consecutive outputs per lane.  The R windows of a lane overlap
+// (Nd + (R-1) L samples instead of R Nd), so a lane streams ITS window once (two ds_read_b128 per
+// 4 samples) and feeds R accumulator pairs; output r uses tap j - L r for window sample j, read
+// as aligned ds_read_b128 from a copy of the taps shifted by L r (zero outside [0, Nd): adding
+// 0*x never changes a float sum).  The lane stride in LDS is padded to an odd multiple of 16
+// bytes so that 8 lanes' b128 reads cover all 32 banks.  Same summation order as the reference:
+// one accumulator per output and component, taps in ascending order.
+constexpr int kLateMaxTaps = 96;
+constexpr int kLateTapRow = 124; // shifted tap copies: u = i + L r < Nd + 3 L = 114 (+ b128 overrun), a multiple of 4
+__host__ __device__ constexpr int late4_pad(int R, int L) { return (2 * R * L) % 8 == 4 ? 0 : 2; } // float2 per R L samples
+__host__ __device__ constexpr int late4_lds_bytes(int R, int L, int ndec) // for the launch's largest L and Nd
+{
+    const int span = L * (64 * R - 1) + ndec + (R - 1) * L;
+    return 4 * R * kLateTapRow + 8 * (span + 2 * (span / (R * L)) + 8);
+}
+
+template <bool EXACT, int L, int R>
+__device__ __forceinline__ void late4_body(const float2 *__restrict__ x, float2 *__restrict__ zout, const float *__restrict__ taps, int n, int ndec,
+                                           int n_out, int k0, int lane, v2f *__restrict__ sx, float *__restrict__ sh)
+{
+    constexpr int kPad = late4_pad(R, L);
+    constexpr int kStride = R * L + kPad;                                          // float2 per lane
+    constexpr int kIters = (L * (64 * R - 1) + kLateMaxTaps + (R - 1) * L + 63) / 64; // window loads per lane
+    constexpr int kTapIters = (R * kLateTapRow + 63) / 64;
+    const int lo = L * k0 - ndec;                       // first input index of the tile's window (>= -Hx)
+    const int span = L * (64 * R - 1) + ndec + (R - 1) * L; // lanes' windows end at lo + R L lane + ndec + (R-1) L
+    // every load of the lane is issued before the first LDS write (see k_usb_demod)
+    v2f stage[kIters];
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+        const int t = lane + 64 * it, idx = lo + t;
+        const v2f z2 = {0.f, 0.f};
+        stage[it] = (t < span && idx < n) ? gldv2(x + idx) : z2;
+    }
+    float hst[kTapIters];
+#pragma unroll
+    for (int it = 0; it < kTapIters; ++it) {
+        const int u = lane + 64 * it;
+        const int r = u / kLateTapRow, i = u - r * kLateTapRow - L * r;
+        hst[it] = (u < R * kLateTapRow && i >= 0 && i < ndec) ? gld(taps + i) : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+        const int t = lane + 64 * it;
+        if (t < span)
+            sx[t + kPad * (t / (R * L))] = stage[it];
+    }
+#pragma unroll
+    for (int it = 0; it < kTapIters; ++it) {
+        const int u = lane + 64 * it;
+        if (u < R * kLateTapRow)
+            sh[u] = hst[it];
+    }
+    wave_sync();
+    const int k = k0 + R * lane;
+    if (k >= n_out)
+        return;
+    const v2f *w = sx + kStride * lane; // window sample j sits at w[j + kPad * (j / (R L))]
+    v2f acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        acc[r] = v2f{0.f, 0.f};
+    const int groups = (ndec + (R - 1) * L + 3) / 4;
+    for (int g = 0; g < groups; ++g) {
+        const int j = 4 * g;
+        const v4f a = *reinterpret_cast<const v4f *>(w + j + kPad * (j / (R * L)));
+        const v4f b = *reinterpret_cast<const v4f *>(w + j + 2 + kPad * ((j + 2) / (R * L)));
+        const v2f xs[4] = {lo2(a), hi2(a), lo2(b), hi2(b)};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const v4f h4 = *reinterpret_cast<const v4f *>(sh + r * kLateTapRow + j);
+            const float h[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const v2f hh = {h[e], h[e]};
+                if (EXACT)
+                    acc[r] = acc[r] + hh * xs[e];
+                else
+                    acc[r] = __builtin_elementwise_fma(hh, xs[e], acc[r]);
+            }
+        }
+    }
+    if (k + R - 1 < n_out) {
+#pragma unroll
+        for (int r = 0; r < R; r += 2)
+            gstv4(reinterpret_cast<float4 *>(zout + k + r), cat2(acc[r], acc[r + 1]));
+    } else {
+        for (int r = 0; r < R && k + r < n_out; ++r)
+            gstv2(zout + k + r, acc[r]);
+    }
+}
+
+#ifndef SDRX_LATE4_WAVES
+#define SDRX_LATE4_WAVES 6 // 76 VGPRs; measured 34.0 us vs 35.4 (5 waves) and 35.5 (8 waves) on config 4
+#endif
+template <bool EXACT, int R>
+__global__ __launch_bounds__(64, SDRX_LATE4_WAVES) void k_late_decimate4(const K2aVfo *__restrict__ vfos, const BlockWork *__restrict__ work,
+                                                       unsigned long long frame_no)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *sh = reinterpret_cast<float *>(smem);
+    v2f *sx = reinterpret_cast<v2f *>(smem + 4 * R * kLateTapRow);
+    const BlockWork bw = work[blockIdx.x];
+    const K2aVfo *Dp = vfos + bw.vfo;
+    const int par = (int)(frame_no & 1ull);
+    const int lane = threadIdx.x;
+    struct {
+        const float *taps;
+        int Hx, n, ndec, L, n_out;
+    } D = {Dp->taps, Dp->Hx, Dp->n, Dp->ndec, Dp->L, Dp->n_out};
+    const float2 *xbase = Dp->x[par];
+    float2 *xnext = Dp->x_next[par];
+    const int k0 = bw.blk * 64 * R;
+    if (k0 >= D.n_out && bw.blk != 0)
+        return;
+    if (bw.blk == 0) // history for the next frame: the last Hx entries of [hist | data]
+        for (int j = lane; j < D.Hx; j += 64)
+            gst2(xnext + j, gld2(xbase + D.n + j));
+    if (D.L == 5)
+        late4_body<EXACT, 5, R>(xbase + D.Hx, Dp->z[par], D.taps, D.n, D.ndec, D.n_out, k0, lane, sx, sh);
+    else
+        late4_body<EXACT, 6, R>(xbase + D.Hx, Dp->z[par], D.taps, D.n, D.ndec, D.n_out, k0, lane, sx, sh);
+}
+
 // USB demodulation + optional audio low-pass + int16 (vfo.cpp:300-332):
 //   usb[m]  = I[m-62] - sum_{i<125} hp[i] Q[m-124+i]      DelayThing (dsp.h:101-106) and
 //                                                         FIRHilbert (dsp.cpp:218-231, newest
@@ -840,10 +965,7 @@ constexpr int kDemodTile = 1024;
 constexpr int kPlaneLen = (kDemodTile + kMaxFir + kHilbert + 1) / 2 + 8;
 
 template <bool EXACT>
-#ifndef SDRX_DEMOD_WAVES
-#define SDRX_DEMOD_WAVES 1
-#endif
-__global__ __launch_bounds__(256, SDRX_DEMOD_WAVES) void k_usb_demod(const K2Vfo *__restrict__ vfos, const BlockWork *__restrict__ work,
+__global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfos, const BlockWork *__restrict__ work,
                                                    unsigned long long frame_no)
 {
     __shared__ __attribute__((aligned(16))) float sP0[kPlaneLen + 4]; // even offsets from `lo`, stored shifted by +3
@@ -886,16 +1008,27 @@ __global__ __launch_bounds__(256, SDRX_DEMOD_WAVES) void k_usb_demod(const K2Vfo
     const int ntv = kDemodTile + E;
     const int lo = m0 - E - (kHilbert - 1);     // first stream index touched (>= -H)
     const int nr = ntv + (kHilbert - 1);        // offsets r = idx - lo in [0, nr)
-    for (int r = tid; r < nr; r += 256) {
-        const int idx = lo + r;
-        const float2 v = idx < D.n ? gld2(z + idx) : make_float2(0.f, 0.f);
-        if (r & 1)
-            sP1[r >> 1] = v.y;
-        else
-            sP0[(r >> 1) + 3] = v.y;
-        const int t = r - kDelay;               // I[u-62] for u = m0 - E + t
-        if (t >= 0 && t < ntv)
-            sI[t] = v.x;
+    // all of this thread's loads are issued before the first LDS write (a rolled load -> wait ->
+    // write loop would pay the memory latency once per iteration)
+    constexpr int kStageIters = (kDemodTile + kMaxFir + kHilbert + 255) / 256;
+    float2 stage[kStageIters];
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+        const int r = tid + 256 * it, idx = lo + r;
+        stage[it] = (r < nr && idx < D.n) ? gld2(z + idx) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+        const int r = tid + 256 * it;
+        if (r < nr) {
+            if (r & 1)
+                sP1[r >> 1] = stage[it].y;
+            else
+                sP0[(r >> 1) + 3] = stage[it].y;
+            const int t = r - kDelay;           // I[u-62] for u = m0 - E + t
+            if (t >= 0 && t < ntv)
+                sI[t] = stage[it].x;
+        }
     }
     __syncthreads();
 

@@ -101,6 +101,8 @@ struct sdrx_ctx {
     size_t pay_bytes = 0;
     float2 *d_raw = nullptr;       // staging for host-fed frames (natural order)
     float2 *d_raw_tiled = nullptr; // the raw frame in tile layout: input of the parent-less VFOs
+    bool late4 = false;            // k_late_decimate4 serves the late-decimation launch
+    int late4_r = 4;               // outputs per lane of that kernel
     bool root_direct = false;      // level 0 reads the caller's natural-order frame itself (few VFOs)
     unsigned char *d_raw_u8 = nullptr;
     float *d_dc_state = nullptr;   // DC-bias accumulator (exact: [2]; fast: [parity][2])
@@ -252,7 +254,14 @@ int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode)
         Bracket b(c, L.kind, L.alg_bytes);
         const dim3 grid(L.n_blocks);
         const BlockWork *w = reinterpret_cast<const BlockWork *>(c->arena + L.off_work);
-        if (L.kind == KIND_LATE_DEC)
+        if (L.kind == KIND_LATE_DEC && c->late4)
+            if (c->late4_r == 2)
+                hipLaunchKernelGGL((k_late_decimate4<EXACT, 2>), grid, dim3(64), L.lds_bytes, c->stream,
+                                   reinterpret_cast<const K2aVfo *>(c->arena + L.off_desc), w, c->frame_no);
+            else
+                hipLaunchKernelGGL((k_late_decimate4<EXACT, 4>), grid, dim3(64), L.lds_bytes, c->stream,
+                                   reinterpret_cast<const K2aVfo *>(c->arena + L.off_desc), w, c->frame_no);
+        else if (L.kind == KIND_LATE_DEC)
             hipLaunchKernelGGL(k_late_decimate<EXACT>, grid, dim3(256), L.lds_bytes, c->stream,
                                reinterpret_cast<const K2aVfo *>(c->arena + L.off_desc), w, c->frame_no);
         else if (L.kind == KIND_DEMOD)
@@ -634,13 +643,31 @@ int sdrx_finalize(sdrx_ctx *c)
     std::vector<int> n2a, n2, n3; // node index of each descriptor
     int64_t b2a = 0, b2 = 0, b3 = 0;
     int lds2a = 0;
+    // every late-decimating VFO has L in {5,6} and <= 96 taps: one-wave tiles, R outputs per lane
+    bool late4 = !getenv("SDRX_NO_LATE4");
+    for (const Node &n : c->nodes)
+        if (n.leaf && n.d.demod_usb && n.d.late_decimate > 0)
+            late4 = late4 && (n.d.late_decimate == 5 || n.d.late_decimate == 6) && (int)n.dec.size() <= kLateMaxTaps;
+    c->late4 = late4;
+    // 2 outputs per lane (8 KB of LDS per wave, ~20 waves per CU) measured 38 us on config 4, 4 outputs
+    // per lane (fewer LDS reads, 16 KB, 10 waves per CU) 48 us, the one-output-per-thread kernel 54 us
+    c->late4_r = getenv("SDRX_LATE4_R") ? atoi(getenv("SDRX_LATE4_R")) : 2;
+    if (c->late4_r != 4)
+        c->late4_r = 2;
+    int late_lmax = 5, late_ndec = 0;
+    for (const Node &n : c->nodes)
+        if (n.leaf && n.d.demod_usb && n.d.late_decimate > 0) {
+            late_lmax = std::max(late_lmax, n.d.late_decimate);
+            late_ndec = std::max(late_ndec, (int)n.dec.size());
+        }
+    const int late_tile = late4 ? 64 * c->late4_r : 256;
     for (int i = 0; i < N; ++i) {
         Node &n = c->nodes[(size_t)i];
         if (!n.leaf)
             continue;
         if (n.d.demod_usb) {
             if (n.d.late_decimate > 0) {
-                for (int b = 0; b < (n.n_out + 255) / 256; ++b)
+                for (int b = 0; b < (n.n_out + late_tile - 1) / late_tile; ++b)
                     w2a.push_back({(int)d2a.size(), b});
                 n2a.push_back(i);
                 d2a.push_back(K2aVfo{});
@@ -664,7 +691,7 @@ int sdrx_finalize(sdrx_ctx *c)
     if (!d2a.empty()) {
         o2a = plan.take(sizeof(K2aVfo) * d2a.size());
         ow2a = plan.take(sizeof(BlockWork) * w2a.size());
-        c->lb.push_back({KIND_LATE_DEC, (int)w2a.size(), o2a, ow2a, lds2a, b2a});
+        c->lb.push_back({KIND_LATE_DEC, (int)w2a.size(), o2a, ow2a, c->late4 ? late4_lds_bytes(c->late4_r, late_lmax, late_ndec) : lds2a, b2a});
     }
     if (!d2.empty()) {
         o2 = plan.take(sizeof(K2Vfo) * d2.size());
