@@ -3,7 +3,8 @@
 // frames to sdrj::demodData, receive every leaf's payload through the publish hook.
 //
 //   sdrx_demo <profile.ini> --dump              descriptors as JSON lines (no GPU needed)
-//   sdrx_demo <profile.ini> --frames N [--u8]   N synthetic LCG frames; one line per published
+//   sdrx_demo <profile.ini> --frames N [--u8] [--fft TOPIC]
+//                                               N synthetic LCG frames; one line per published
 //                                               message: frame topic rate bytes fnv1a64(payload)
 #include <cinttypes>
 #include <cstdio>
@@ -55,7 +56,14 @@ int main(int argc, char **argv)
         if (mode != "--frames" || argc < 4)
             throw std::runtime_error("bad arguments");
         const int frames = std::atoi(argv[3]);
-        const bool u8 = argc > 4 && std::string(argv[4]) == "--u8";
+        bool u8 = false;
+        std::string fft_topic;
+        for (int a = 4; a < argc; ++a) {
+            if (std::string(argv[a]) == "--u8")
+                u8 = true;
+            else if (std::string(argv[a]) == "--fft" && a + 1 < argc)
+                fft_topic = argv[++a];
+        }
         sdrj radio(0);
         radio.setVFOs(&P->mains);
         radio.setDCCorrection(P->correct_dc);
@@ -65,6 +73,21 @@ int main(int argc, char **argv)
             std::memcpy(t, topic, 5);
             std::printf("%d %s %u %u %016" PRIx64 "\n", frame_no, t, rate, len, fnv1a(buf, len));
         });
+        // --fft TOPIC: what the GUI's spectrum selector does -- every vfo and the sdrj get fftVFOSlot(TOPIC)
+        auto tap = [&](const char *who) {
+            return [&frame_no, who](const std::vector<std::complex<float>> &d) {
+                std::printf("fft %d %s %zu %016" PRIx64 "\n", frame_no, who, d.size(), fnv1a(d.data(), d.size() * sizeof(d[0])));
+            };
+        };
+        if (!fft_topic.empty()) {
+            for (auto &up : P->all) {
+                vfo *v = up.get();
+                v->fftData = tap(v->topic.c_str());
+                v->fftVFOSlot(fft_topic);
+            }
+            radio.fftData = tap("Main");
+            radio.fftVFOSlot(fft_topic);
+        }
         // synthetic IQ of BASELINE.md: LCG x <- x*1664525 + 1013904223, component ((x >> 24) % 17) - 8
         uint32_t x = 1;
         std::vector<float> iq((size_t)2 * P->frame);

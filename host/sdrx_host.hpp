@@ -9,6 +9,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -61,6 +62,11 @@ public:
         initialised = true;
     }
     void setVFOs(std::vector<vfo *> *pVFOs) { mpVFOs = pVFOs; }
+    // vfo.cpp:492-509: decimate[decimateCount] goes to fftData after every frame while the selected
+    // topic is this VFO's own (the Qt signal of vfo.h:46 is a plain callback here)
+    void fftVFOSlot(const std::string &t) { emitFFT = t == topic; }
+    std::function<void(const std::vector<std::complex<float>> &)> fftData;
+    bool emitFFT = false;
 
     sdrx_vfo_desc d;
     std::string topic, zmqAddress;
@@ -88,6 +94,14 @@ public:
     void setDCCorrection(bool dc) { correctDC = dc; }
     void setPublisher(publish_fn f) { publish_ = std::move(f); }
     void setOption(const std::string &name, int value) { options_[name] = value; }
+    // sdrj.cpp:84-101: the raw spectrum is selected by the topic "Main"; any selection restarts
+    // the every-4th-call counter of demodData (sdrj.cpp:296-303)
+    void fftVFOSlot(const std::string &topic)
+    {
+        emitFFT = topic == "Main";
+        count = 0;
+    }
+    std::function<void(const std::vector<std::complex<float>> &)> fftData; // signal of sdrj.h:40
 
     // Commit the tree to the GPU (== all vfo::init work).  Called by the first demodData.
     void start()
@@ -121,6 +135,7 @@ public:
             in = samples_.data();
         }
         check(sdrx_process(ctx_, in, len / 2), "sdrx_process");
+        after_frame(len / 2);
     }
     // rtl_tcp / dongle bytes (sdrj.cpp:149-165): LUT and DC correction on the device.
     void demodBytes(const uint8_t *bytes, int n_complex)
@@ -128,12 +143,38 @@ public:
         if (!ctx_)
             start();
         check(sdrx_process_u8(ctx_, bytes, n_complex, correctDC ? 1 : 0), "sdrx_process_u8");
+        after_frame(n_complex);
     }
     sdrx_ctx *context() { return ctx_; }
 
 private:
+    // vfo::process ends with `if (emitFFT) emit fftData(decimate[decimateCount])` (vfo.cpp:290-293);
+    // demodData with `if (count == 4 && emitFFT) { emit fftData(samples); count = 0; } count++`.
+    void after_frame(int n_complex)
+    {
+        for (vfo *v : all_)
+            if (v->emitFFT && v->fftData) {
+                int n = 0;
+                check(sdrx_get_stream(ctx_, v->id, nullptr, 0, &n), "sdrx_get_stream");
+                tap_.resize((size_t)n);
+                check(sdrx_get_stream(ctx_, v->id, reinterpret_cast<float *>(tap_.data()), n, &n), "sdrx_get_stream");
+                v->fftData(tap_);
+            }
+        if (count == 4 && emitFFT) {
+            if (fftData) {
+                int n = 0;
+                tap_.resize((size_t)n_complex);
+                check(sdrx_get_raw(ctx_, reinterpret_cast<float *>(tap_.data()), n_complex, &n), "sdrx_get_raw");
+                tap_.resize((size_t)n);
+                fftData(tap_);
+            }
+            count = 0;
+        }
+        count++;
+    }
     void add(vfo *v, int parent)
     {
+        all_.push_back(v);
         if (!v->initialised)
             throw std::runtime_error("vfo::init was not called");
         v->d.parent_id = parent;
@@ -157,6 +198,10 @@ private:
     sdrx_ctx *ctx_ = nullptr;
     std::vector<vfo *> *mpVFOs = nullptr;
     bool correctDC = false;
+    bool emitFFT = false;
+    int count = 0;
+    std::vector<vfo *> all_;
+    std::vector<std::complex<float>> tap_;
     float avept_[2] = {0.f, 0.f};
     std::vector<float> samples_;
     publish_fn publish_;

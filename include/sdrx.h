@@ -129,6 +129,12 @@ int sdrx_get_output(sdrx_ctx *ctx, int id, const void **buf, uint32_t *len_bytes
 /* decimate[decimateCount] of node `id` (public member vfo.h:39 -- what the fftData signal
  * carries, vfo.cpp:290-293): copies up to max_complex cf32 to `out`, returns the count in *n. */
 int sdrx_get_stream(sdrx_ctx *ctx, int id, float *out_iq, int max_complex, int *n);
+/* The raw frame exactly as the parent-less VFOs consumed it -- `samples` of sdrj::demodData
+ * (sdrj.cpp:266-305) after the byte LUT and the DC-bias removal, what sdrj's own fftData signal
+ * carries (sdrj.cpp:296-303) -- natural order, cf32.  Available after sdrx_process and
+ * sdrx_process_u8; after sdrx_process_device the frame was the caller's own device memory and
+ * the call returns SDRX_ESTATE. */
+int sdrx_get_raw(sdrx_ctx *ctx, float *out_iq, int max_complex, int *n);
 int sdrx_get_prequant(sdrx_ctx *ctx, int id, float *out, int max, int *n);
 /* Designed tap sets, for parity checks: which = 0 audio low-pass, 1 late-decimation low-pass,
  * 2 Hilbert. */

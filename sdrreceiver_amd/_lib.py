@@ -53,6 +53,7 @@ SYMBOLS = {
     "sdrx_set_stream": (_i, [_vp, _vp]),
     "sdrx_get_output": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sdrx_get_stream": (_i, [_vp, _i, _vp, _i, C.POINTER(_i)]),
+    "sdrx_get_raw": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     "sdrx_get_prequant": (_i, [_vp, _i, _vp, _i, C.POINTER(_i)]),
     "sdrx_get_taps": (_i, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "sdrx_get_nco": (_i, [_vp, _i, C.c_long, C.c_long, _vp]),

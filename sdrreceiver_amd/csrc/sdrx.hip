@@ -101,6 +101,7 @@ struct sdrx_ctx {
     size_t pay_bytes = 0;
     float2 *d_raw = nullptr;       // staging for host-fed frames (natural order)
     float2 *d_raw_tiled = nullptr; // the raw frame in tile layout: input of the parent-less VFOs
+    int last_raw = -1;             // how the last frame reached level 0 (kRaw*; -1: caller-owned device memory)
     bool late4 = false;            // k_late_decimate4 serves the late-decimation launch
     int late4_r = 4;               // outputs per lane of that kernel
     bool root_direct = false;      // level 0 reads the caller's natural-order frame itself (few VFOs)
@@ -853,6 +854,7 @@ int sdrx_process_device(sdrx_ctx *c, const void *dev_iq, int n_complex)
     if (!dev_iq)
         return fail(c, SDRX_EINVAL, "null frame pointer");
     HIPCHK(c, hipSetDevice(c->device));
+    c->last_raw = -1;
     return c->opt_exact ? enqueue_frame<true>(c, dev_iq, kRawF32) : enqueue_frame<false>(c, dev_iq, kRawF32);
 }
 
@@ -910,6 +912,7 @@ int sdrx_process(sdrx_ctx *c, const float *iq, int n_complex)
     rc = sdrx_process_device(c, c->d_raw, n_complex);
     if (rc)
         return rc;
+    c->last_raw = kRawF32;
     return sdrx_fetch(c);
 }
 
@@ -966,6 +969,7 @@ int sdrx_process_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correc
     rc = c->opt_exact ? enqueue_frame<true>(c, c->d_raw_u8, mode) : enqueue_frame<false>(c, c->d_raw_u8, mode);
     if (rc)
         return rc;
+    c->last_raw = mode;
     return sdrx_fetch(c);
 }
 
@@ -989,6 +993,40 @@ int sdrx_get_output(sdrx_ctx *c, int id, const void **buf, uint32_t *len, uint32
         *len = n.pay_len;
     if (rate)
         *rate = n.rate;
+    return SDRX_OK;
+}
+
+int sdrx_get_raw(sdrx_ctx *c, float *out, int max_complex, int *n_ret)
+{
+    if (!c || !out)
+        return SDRX_EINVAL;
+    if (!c->finalized || c->frame_no == 0)
+        return fail(c, SDRX_ESTATE, "sdrx_get_raw: no frame processed yet");
+    if (c->last_raw < 0)
+        return fail(c, SDRX_ESTATE, "sdrx_get_raw: the last frame was caller-owned device memory (sdrx_process_device)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = std::min(max_complex, c->root_frame);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->last_raw == kRawF32) {
+        HIPCHK(c, hipMemcpy(out, c->d_raw, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
+    } else if (c->last_raw == kRawU8) { // floats[b] = b - 127, jonti/sdr.cpp:43-49
+        std::vector<uint8_t> b((size_t)n * 2);
+        HIPCHK(c, hipMemcpy(b.data(), c->d_raw_u8, b.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < b.size(); ++i)
+            out[i] = (float)((int)b[i] - 127);
+    } else { // tile layout (the DC-bias kernels wrote it): unit (chunk, i2, lane) = samples 16 lane + 2 i2, +1
+        const size_t total = align_up((size_t)c->root_frame, kChunk);
+        std::vector<float2> t(total);
+        HIPCHK(c, hipMemcpy(t.data(), c->d_raw_tiled, total * sizeof(float2), hipMemcpyDeviceToHost));
+        for (int g = 0; g < n; ++g) {
+            const int ch = g >> 10, r = g & 1023, ln = r >> 4, i = r & 15;
+            const float2 v = t[(size_t)ch * 1024 + (size_t)(i >> 1) * 128 + (size_t)ln * 2 + (size_t)(i & 1)];
+            out[2 * g] = v.x;
+            out[2 * g + 1] = v.y;
+        }
+    }
+    if (n_ret)
+        *n_ret = n;
     return SDRX_OK;
 }
 

@@ -135,6 +135,16 @@ class Receiver:
         self._chk(self.L.sdrx_get_stream(self.h, vid, out.ctypes.data, n.value, C.byref(n)))
         return out[: 2 * n.value].view(np.complex64).copy()
 
+    def raw(self) -> np.ndarray:
+        """The raw frame as the main VFOs consumed it (after the byte LUT / DC-bias removal)."""
+        out = np.zeros(2 * self.root_frame(), np.float32)
+        n = C.c_int()
+        self._chk(self.L.sdrx_get_raw(self.h, out.ctypes.data, out.size // 2, C.byref(n)))
+        return out[: 2 * n.value].view(np.complex64).copy()
+
+    def root_frame(self) -> int:
+        return max(d.samples_per_buffer for d in self.descs if d.parent < 0)
+
     def prequant(self, vid: int) -> np.ndarray:
         n = C.c_int()
         self._chk(self.L.sdrx_get_prequant(self.h, vid, None, 0, C.byref(n)))
@@ -187,6 +197,8 @@ class vfo:  # noqa: N801  (the reference's class name, vfo.h:11)
         self._radio: "sdrj | None" = None
         self._id = -1
         self._init = False
+        self.emitFFT = False
+        self.fftData = None  # callable(np.ndarray complex64): the Qt signal of vfo.h:46
 
     def setFs(self, samplerate): self.desc.fs = int(samplerate)
     def setDecimationCount(self, count): self.desc.decimate_count = int(count)
@@ -209,6 +221,11 @@ class vfo:  # noqa: N801  (the reference's class name, vfo.h:11)
 
     def setVFOs(self, pVFOs):
         self.children = list(pVFOs)
+
+    def fftVFOSlot(self, topic):
+        """vfo.cpp:492-509: this VFO's decimate[decimateCount] goes to ``fftData`` after every
+        frame while the selected topic is its own."""
+        self.emitFFT = str(topic) == self.desc.topic
 
     # observation, available once the owning sdrj has started
     def _r(self) -> Receiver:
@@ -237,9 +254,37 @@ class sdrj:  # noqa: N801  (the reference's class name, sdrj.h)
         self.correctDC = False
         self._avept = np.zeros(2, np.float32)
         self._kw = dict(device=device, exact=exact, keep_prequant=keep_prequant)
+        self.emitFFT = False
+        self.count = 0
+        self.fftData = None  # callable(np.ndarray complex64): the Qt signal of sdrj.h:40
 
     def setVFOs(self, vfos): self.mains = list(vfos)
     def setDCCorrection(self, dc): self.correctDC = bool(dc)
+
+    def fftVFOSlot(self, topic):
+        """sdrj.cpp:84-101: the raw spectrum is selected by the topic "Main"; any selection
+        restarts the every-4th-call counter."""
+        self.emitFFT = str(topic) == "Main"
+        self.count = 0
+
+    def _all_vfos(self):
+        stack = list(self.mains)
+        while stack:
+            v = stack.pop(0)
+            yield v
+            stack[0:0] = v.children
+
+    def _after_frame(self):
+        # vfo::process ends with `if (emitFFT) emit fftData(decimate[decimateCount])` (vfo.cpp:290-293),
+        # demodData with the every-4th-call raw tap (sdrj.cpp:296-303)
+        for v in self._all_vfos():
+            if v.emitFFT and v.fftData is not None:
+                v.fftData(self.rx.stream(v._id))
+        if self.count == 4 and self.emitFFT:
+            if self.fftData is not None:
+                self.fftData(self.rx.raw())
+            self.count = 0
+        self.count += 1
 
     def start(self):
         self.rx = Receiver(**self._kw)
@@ -269,6 +314,15 @@ class sdrj:  # noqa: N801  (the reference's class name, sdrj.h)
             data = data.copy()
             _dc_correct(data, self._avept)
         self.rx.process(data)
+        self._after_frame()
+
+    def demodBytes(self, data):
+        """The rtl_tcp byte stream (sdrj.cpp:155-160 feeds it through the LUT into demodData):
+        LUT and DC-bias removal run on the device."""
+        if self.rx is None:
+            self.start()
+        self.rx.process_u8(np.ascontiguousarray(data, dtype=np.uint8).reshape(-1), correct_dc=self.correctDC)
+        self._after_frame()
 
     @property
     def published(self):

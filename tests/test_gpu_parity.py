@@ -301,6 +301,53 @@ def test_reference_named_interface(Receiver):
 
 
 # ------------------------------------------------------------------------------ errors
+def test_fft_taps_of_the_mirror_classes(Receiver):
+    """vfo::fftVFOSlot / fftData (vfo.cpp:290-293,492-509) and sdrj::fftVFOSlot / fftData
+    (sdrj.cpp:84-101,296-303) through the Python mirror, float and byte input."""
+    from sdrreceiver_amd.receiver import sdrj, vfo
+    topo = tp.config1()
+    for use_bytes in (False, True):
+        nodes = []
+        for d in topo.vfos:
+            v = vfo()
+            v.setFs(d.fs); v.setDecimationCount(d.decimate_count); v.setMixerFreq(d.mixer_freq)
+            v.setFilterBandwidth(d.filter_bw); v.setGain(d.gain); v.setDemodUSB(d.demod_usb)
+            v.setCompressonStyle(d.cstyle); v.setScaleComp(d.scalecomp); v.setZmqTopic(d.topic)
+            v.init(d.samples_per_buffer, False, d.late_decimate)
+            nodes.append(v)
+        nodes[0].setVFOs([nodes[1]])
+        radio = sdrj()
+        radio.setVFOs([nodes[0]])
+        radio.setDCCorrection(True)
+        got_vfo, got_raw = [], []
+        nodes[1].fftData = lambda a: got_vfo.append(a)
+        nodes[0].fftData = lambda a: got_vfo.append("main must stay silent")
+        radio.fftData = lambda a: got_raw.append(a)
+        for n in nodes:
+            n.fftVFOSlot(topo.vfos[1].topic)
+        radio.fftVFOSlot("Main")
+        onodes, oroots = ob.build_tree("port", topo)
+        lcg = synth.Lcg(3)
+        state = np.zeros(2, np.float32)
+        raws = []
+        for f in range(9):
+            if use_bytes:
+                b = synth.lcg_frame_u8(topo.frame, lcg)
+                radio.demodBytes(b)
+                iq = ob.u8_to_float(b)
+                ob.dc_correct(iq, state)
+            else:
+                iq = synth.lcg_frame(topo.frame, lcg)
+                radio.demodData(iq, iq.size)
+                ob.dc_correct(iq, state)
+            ob.process_roots(oroots, iq)
+            raws.append(iq.view(np.complex64).copy())
+            assert len(got_vfo) == f + 1 and np.array_equal(bits(got_vfo[-1]), bits(onodes[1].stream()))
+        assert len(got_raw) == 2  # calls 5 and 9
+        assert np.array_equal(bits(got_raw[0]), bits(raws[4])) and np.array_equal(bits(got_raw[1]), bits(raws[8]))
+        radio.rx.close()
+
+
 def test_error_behaviour(Receiver):
     from sdrreceiver_amd.receiver import SdrxError
     t = tp.config1()

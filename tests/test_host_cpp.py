@@ -125,3 +125,38 @@ def test_cpp_host_end_to_end(u8, tmp_path):
             want.append([str(f), topic.rstrip(b"\0").decode(), str(rate), str(len(payload)), f"{_fnv1a(payload):016x}"])
     rx.close()
     assert got == want
+
+
+@pytest.mark.gpu
+def test_cpp_host_fft_taps(tmp_path):
+    """fftVFOSlot / fftData of vfo (vfo.cpp:290-293,492-509: the selected VFO's
+    decimate[decimateCount] after every frame) and of sdrj (sdrj.cpp:84-101,296-303: the raw
+    samples, on the 5th call after the selection and every 4th from then on)."""
+    from oracle import binding as ob
+    from sdrreceiver_amd.receiver import Receiver
+    _build()
+    p = tmp_path / "profile.ini"
+    p.write_text(INI_25E_LIKE)
+    topo = tp.topology_from_ini(INI_25E_LIKE)
+    vid = [i for i, v in enumerate(topo.vfos) if v.topic == "VFO19"][0]
+
+    def run(*extra):
+        out = subprocess.check_output([DEMO, str(p), "--frames", "9", *extra], text=True)
+        return [l.split() for l in out.splitlines() if l.startswith("fft ")]
+
+    rx = Receiver.from_topology(topo)
+    lcg = synth.Lcg(1)
+    state = np.zeros(2, np.float32)
+    want_vfo, want_raw = [], []
+    for f in range(9):
+        iq = synth.lcg_frame(topo.frame, lcg)
+        ob.dc_correct(iq, state)
+        rx.process(iq)
+        st = rx.stream(vid)
+        want_vfo.append(["fft", str(f), "VFO19", str(st.size), f"{_fnv1a(st.tobytes()):016x}"])
+        if f in (4, 8):
+            want_raw.append(["fft", str(f), "Main", str(topo.frame), f"{_fnv1a(iq.tobytes()):016x}"])
+    rx.close()
+    assert run("--fft", "VFO19") == want_vfo
+    assert run("--fft", "Main") == want_raw
+    assert run("--fft", "NOSUCH") == []
