@@ -1,0 +1,169 @@
+// host/qt/dropin_client.cpp -- TEST INFRASTRUCTURE for the drop-in claim.
+//
+// A client of `class vfo` that uses ONLY the public interface of the reference's vfo.h
+// (vfo.h:16-49), the way MainWindow (mainwindow.cpp:98-233) and sdrj::demodData
+// (sdrj.cpp:288-294) do: setters, init(samplesPerBuffer, bind, lateDecimate), setVFOs,
+// process(samples) on every main VFO, the fftVFOSlot slot and the fftData signal.  What the
+// receiver publishes is observed where a real subscriber sees it: on a ZMQ SUB socket.
+//
+// The same file is linked twice (host/qt/Makefile):
+//   oracle/_ref/libdropin_ref.so   with the reference's own vfo.cpp / DSP sources
+//   oracle/_ref/libdropin_sdrx.so  with host/qt/vfo_adapter.cpp over libsdrx.so (the GPU)
+// Same client, same header, same ZmqPublisher: the message streams must be byte-identical.
+#include <QVector>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <unistd.h>
+
+#include "vfo.h"
+#include "zmq.h"
+
+#include "../../include/sdrx.h" // only for the plain description struct sdrx_vfo_desc
+
+namespace {
+void put32(std::vector<unsigned char> &o, uint32_t v)
+{
+    unsigned char b[4];
+    std::memcpy(b, &v, 4);
+    o.insert(o.end(), b, b + 4);
+}
+uint64_t fnv1a(const void *p, size_t n)
+{
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) {
+        h ^= b[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+} // namespace
+
+extern "C" {
+
+// Build the tree described by descs[0..n) (parents before children, parent_id = index or -1),
+// run `frames` frames of the BASELINE LCG signal through every main VFO and return everything a
+// subscriber of `addr` received:  for every message  u32 nparts, then per part u32 len + bytes.
+// fft_topic (may be empty) is handed to every vfo's fftVFOSlot; each fftData emission is logged
+// to fft_out as "frame topic count fnv1a64\n".  Returns the number of bytes written to out, or
+// < 0 on error.
+int dropin_run(const sdrx_vfo_desc *descs, int n, const char *addr, int frames, const char *fft_topic, unsigned char *out, int cap,
+               char *fft_out, int fft_cap)
+{
+    std::vector<vfo *> nodes((size_t)n);
+    std::vector<QVector<vfo *> *> kids((size_t)n, nullptr);
+    QVector<vfo *> mains;
+    std::string fftlog;
+    int frame_no = 0;
+    int root_frame = 0;
+    for (int i = 0; i < n; ++i) {
+        const sdrx_vfo_desc &d = descs[i];
+        vfo *v = new vfo();
+        v->setZmqAddress(QString::fromUtf8(addr));
+        v->setZmqTopic(QString::fromLatin1(d.topic));
+        v->setFs(d.fs);
+        v->setDecimationCount(d.decimate_count);
+        v->setMixerFreq(d.mixer_freq_hz);
+        v->setDemodUSB(d.demod_usb != 0);
+        v->setFilterBandwidth(d.filter_bw_hz);
+        v->setGain(d.gain);
+        v->setCompressonStyle(d.cstyle);
+        v->setScaleComp(d.scalecomp);
+        v->init(d.samples_per_buffer, true, d.late_decimate);
+        nodes[(size_t)i] = v;
+        if (d.parent_id < 0) {
+            mains.append(v);
+            root_frame = d.samples_per_buffer;
+        } else {
+            if (!kids[(size_t)d.parent_id])
+                kids[(size_t)d.parent_id] = new QVector<vfo *>();
+            kids[(size_t)d.parent_id]->append(v);
+        }
+        const std::string topic = d.topic;
+        QObject::connect(v, &vfo::fftData, [&fftlog, &frame_no, topic](const std::vector<cpx_typef> &data) {
+            char line[128];
+            snprintf(line, sizeof line, "%d %s %zu %016llx\n", frame_no, topic.c_str(), data.size(),
+                     (unsigned long long)fnv1a(data.data(), data.size() * sizeof(cpx_typef)));
+            fftlog += line;
+        });
+    }
+    for (int i = 0; i < n; ++i)
+        if (kids[(size_t)i])
+            nodes[(size_t)i]->setVFOs(kids[(size_t)i]);
+    if (fft_topic && fft_topic[0])
+        for (vfo *v : nodes)
+            v->fftVFOSlot(QString::fromLatin1(fft_topic));
+
+    // the subscriber; PUB/SUB joins asynchronously, so give the connection time before frame 0
+    void *zctx = zmq_ctx_new();
+    void *sub = zmq_socket(zctx, ZMQ_SUB);
+    int hwm = 0, timeout = 300;
+    zmq_setsockopt(sub, ZMQ_RCVHWM, &hwm, sizeof hwm);
+    zmq_setsockopt(sub, ZMQ_RCVTIMEO, &timeout, sizeof timeout);
+    zmq_setsockopt(sub, ZMQ_SUBSCRIBE, "", 0);
+    if (zmq_connect(sub, addr) != 0)
+        return -2;
+    usleep(500 * 1000);
+
+    std::vector<unsigned char> all;
+    std::vector<cpx_typef> samples((size_t)root_frame);
+    std::vector<unsigned char> part(1 << 20);
+    uint32_t x = 1; // BASELINE.md's LCG: x <- x*1664525 + 1013904223, component ((x >> 24) % 17) - 8
+    for (frame_no = 0; frame_no < frames; ++frame_no) {
+        for (auto &s : samples) {
+            x = x * 1664525u + 1013904223u;
+            const float re = (float)((int)((x >> 24) % 17u) - 8);
+            x = x * 1664525u + 1013904223u;
+            const float im = (float)((int)((x >> 24) % 17u) - 8);
+            s = cpx_typef(re, im);
+        }
+        for (vfo *m : mains) // sdrj.cpp:288-294
+            m->process(samples);
+        // drain: everything published for this frame (first recv waits up to the timeout)
+        for (;;) {
+            int r = zmq_recv(sub, part.data(), part.size(), 0);
+            if (r < 0)
+                break;
+            std::vector<std::vector<unsigned char>> parts;
+            parts.emplace_back(part.begin(), part.begin() + r);
+            for (;;) {
+                int more = 0;
+                size_t sz = sizeof more;
+                zmq_getsockopt(sub, ZMQ_RCVMORE, &more, &sz);
+                if (!more)
+                    break;
+                r = zmq_recv(sub, part.data(), part.size(), 0);
+                if (r < 0)
+                    break;
+                parts.emplace_back(part.begin(), part.begin() + r);
+            }
+            put32(all, (uint32_t)parts.size());
+            for (auto &p : parts) {
+                put32(all, (uint32_t)p.size());
+                all.insert(all.end(), p.begin(), p.end());
+            }
+            timeout = 20; // the rest of the frame's messages are already queued
+            zmq_setsockopt(sub, ZMQ_RCVTIMEO, &timeout, sizeof timeout);
+        }
+        timeout = 300;
+        zmq_setsockopt(sub, ZMQ_RCVTIMEO, &timeout, sizeof timeout);
+    }
+    zmq_close(sub);
+    zmq_ctx_term(zctx);
+    for (vfo *m : mains)
+        delete m; // a vfo owns its children (vfo.cpp:49-57)
+    if ((int)all.size() > cap)
+        return -3;
+    std::memcpy(out, all.data(), all.size());
+    if (fft_out && fft_cap > 0) {
+        const size_t k = std::min(fftlog.size(), (size_t)fft_cap - 1);
+        std::memcpy(fft_out, fftlog.data(), k);
+        fft_out[k] = 0;
+    }
+    return (int)all.size();
+}
+
+} // extern "C"

@@ -23,6 +23,14 @@ class VfoDescC(C.Structure):
     ]
 
 
+def desc_to_c(d) -> VfoDescC:
+    """topology.VfoDesc -> struct sdrx_vfo_desc"""
+    return VfoDescC(fs=d.fs, decimate_count=d.decimate_count, mixer_freq_hz=float(d.mixer_freq),
+                    demod_usb=int(d.demod_usb), late_decimate=d.late_decimate, filter_bw_hz=int(d.filter_bw),
+                    gain=float(d.gain), cstyle=d.cstyle, scalecomp=d.scalecomp, parent_id=d.parent,
+                    samples_per_buffer=d.samples_per_buffer, topic=d.topic.encode()[:7])
+
+
 class StatsC(C.Structure):
     """struct sdrx_stats"""
     _fields_ = [

@@ -68,10 +68,7 @@ class Receiver:
 
     # -- configuration --------------------------------------------------------------
     def add_vfo(self, d: VfoDesc) -> int:
-        c = _lib.VfoDescC(fs=d.fs, decimate_count=d.decimate_count, mixer_freq_hz=float(d.mixer_freq),
-                          demod_usb=int(d.demod_usb), late_decimate=d.late_decimate, filter_bw_hz=int(d.filter_bw),
-                          gain=float(d.gain), cstyle=d.cstyle, scalecomp=d.scalecomp, parent_id=d.parent,
-                          samples_per_buffer=d.samples_per_buffer, topic=d.topic.encode()[:7])
+        c = _lib.desc_to_c(d)
         out = C.c_int(-1)
         self._chk(self.L.sdrx_add_vfo(self.h, C.byref(c), C.byref(out)))
         self.descs.append(d)

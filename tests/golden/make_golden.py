@@ -173,9 +173,32 @@ def gen_zmq():
     print("zmq_framing.npz", [len(f) for f in frames], frames[0], frames[1].hex())
 
 
+DROPIN_CASES = [("config1", 3, "VFO01"), ("profile_25e", 3, "VFO19"), ("config4_12", 2, "C0003")]
+
+
+def gen_dropin():
+    """What a ZMQ subscriber receives from the REFERENCE's `class vfo` driven through its public
+    interface by host/qt/dropin_client.cpp (oracle/_ref/libdropin_ref.so, `make -C host/qt`):
+    per message topic bytes, rate, payload length and FNV-1a hash, plus the fftData emissions.
+    The adapter build of the same client (libdropin_sdrx.so, GPU) must reproduce these lines."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(OUT))
+    for name, frames, fft in DROPIN_CASES:
+        out = subprocess.check_output([sys.executable, os.path.join(root, "tools", "dropin_run.py"), "ref", name, str(frames), fft], text=True)
+        lines = [json.loads(l) for l in out.splitlines()]
+        with open(os.path.join(OUT, f"dropin_{name}.json"), "w") as f:
+            json.dump({"frames": frames, "fft_topic": fft, "lines": lines}, f, indent=0)
+        print(f"dropin_{name}.json", len(lines), "lines")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "dropin":
+        gen_dropin()
+        sys.exit(0)
     if not ob.have_reference():
         sys.exit("oracle/_ref/libsdrref.so missing: run `make -C oracle/ref` first (needs /root/reference)")
     gen_primitives()
     gen_chains()
     gen_zmq()
+    gen_dropin()
