@@ -168,6 +168,30 @@ def test_time_segmentation_is_invisible(Receiver):
                 assert np.array_equal(bits(a), bits(b))
 
 
+@pytest.mark.parametrize("key", ["profile_25e", "54w"])
+def test_async_frames_back_to_back(Receiver, key):
+    """sdrx_process_device is asynchronous: 9 frames queued on a caller's stream without any
+    synchronisation in between (level 0 of a frame may start while the previous frame's
+    demodulation is still running), one sdrx_fetch at the end.  Streams and payloads equal the
+    oracle's bit for bit."""
+    import torch
+    topo = golden_topology(key)
+    nodes, roots = ob.build_tree("port", topo)
+    frames = [iq for _, iq in _frames(topo, 9, seed=13)]
+    for iq in frames:
+        ob.process_roots(roots, iq)
+    st = torch.cuda.Stream()
+    rx = Receiver.from_topology(topo, exact=True)
+    rx.set_stream(st.cuda_stream)
+    with torch.cuda.stream(st):
+        dev = [torch.from_numpy(iq).cuda(non_blocking=True) for iq in frames]
+        for d in dev:
+            rx.process_device(d.data_ptr(), topo.frame)
+    rx.fetch()
+    _check_exact(rx, nodes, topo, ("async", key))
+    rx.close()
+
+
 def test_publish_order_and_framing(Receiver):
     """Callback order = main order x sub order (sdrj.cpp:288-294, vfo.cpp:257-263); topic is
     exactly 5 bytes, rate is outputRate, payload is the int16 audio (zmqpublisher.cpp:82-96)."""
