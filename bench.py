@@ -125,13 +125,18 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libsdrx has no CPU fallback)")
+    # SDRX_BENCH_SHARE_GPU=1 (validation on a 1-GPU box only): all ranks on device 0, gloo instead of
+    # RCCL (which refuses two ranks on one device).  The numbers of such a run mean nothing.
+    share = os.environ.get("SDRX_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     from sdrreceiver_amd import distributed as D, synth, topology as tp
     from sdrreceiver_amd.receiver import Receiver
     dist = None
     if world > 1:
         import torch.distributed as dist
-        D.init_process_group("nccl", device=torch.device("cuda", local))
+        D.init_process_group("gloo" if share else "nccl", device=torch.device("cuda", local))
 
     full, descr = make_topology(args.workload, world)
     topo = tp.shard(full, rank, world)
@@ -146,9 +151,15 @@ def main():
     src = torch.from_numpy(frame_np).cuda() if rank == 0 else None
     bcast = D.FrameBroadcast(topo.frame, torch.device("cuda", local), src_rank=0)  # RCCL over xGMI: the only exchange
 
+    # The broadcast of frame k+1 (RCCL, its own stream) overlaps the processing of frame k; at N = 1
+    # submit/result hand the resident frame straight through.
+    bcast.submit(src)
+
     def step(k):
-        b = bcast(src)
+        b = bcast.result()
         rx.process_device(b.data_ptr(), topo.frame)
+        bcast.consumed()
+        bcast.submit(src)
 
     def barrier():
         torch.cuda.synchronize()

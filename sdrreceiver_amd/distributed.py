@@ -38,7 +38,15 @@ def init_process_group(backend: str | None = None, device: torch.device | None =
 
 
 class FrameBroadcast:
-    """Double-buffered broadcast of the raw frame (2*n_complex float32) from `src_rank`."""
+    """Double-buffered broadcast of the raw frame (2*n_complex float32) from `src_rank`.
+
+    Two ways to use it:
+      * ``buf = bc(frame)``: broadcast now, on the current stream (simple, serial);
+      * ``bc.submit(frame)`` ... ``buf = bc.result()`` ... ``bc.consumed()``: the broadcast of the
+        NEXT frame runs on a communication stream of its own while the current frame is being
+        processed.  ``result()`` makes the current (compute) stream wait for the pending broadcast,
+        ``consumed()`` marks, in compute-stream order, the point after which the buffer returned by
+        the previous ``result()`` may be overwritten."""
 
     def __init__(self, n_complex: int, device: torch.device, src_rank: int = 0):
         self.rank = dist.get_rank() if dist.is_initialized() else 0
@@ -46,6 +54,11 @@ class FrameBroadcast:
         self.src = src_rank
         self.buf = [torch.empty(2 * n_complex, dtype=torch.float32, device=device) for _ in range(2)]
         self.k = 0
+        self.cuda = device.type == "cuda"
+        self.comm = torch.cuda.Stream(device) if (self.cuda and self.world > 1) else None
+        self._pending = None            # (buffer, work handle or None)
+        self._free = [None, None]       # per buffer: event after which it may be overwritten
+        self._last = None               # index of the buffer handed out by the last result()
 
     def __call__(self, frame: torch.Tensor | None) -> torch.Tensor:
         """`frame`: the new raw frame on the source rank (ignored elsewhere).  Returns this
@@ -58,6 +71,46 @@ class FrameBroadcast:
             b.copy_(frame, non_blocking=True)
         dist.broadcast(b, src=self.src)
         return b
+
+    # -- overlapped form ------------------------------------------------------------------------
+    def submit(self, frame: torch.Tensor | None) -> None:
+        if self.world == 1:
+            self._pending = (frame, None)
+            return
+        i = self.k & 1
+        self.k += 1
+        b = self.buf[i]
+        if self.comm is None:  # CPU tensors (gloo in the test-suite): nothing to overlap with
+            if self.rank == self.src:
+                b.copy_(frame)
+            self._pending = (b, dist.broadcast(b, src=self.src, async_op=True), i)
+            return
+        with torch.cuda.stream(self.comm):
+            if self._free[i] is not None:
+                self.comm.wait_event(self._free[i])  # the frame that last used this buffer has been consumed
+            if self.rank == self.src:
+                b.copy_(frame, non_blocking=True)
+            work = dist.broadcast(b, src=self.src, async_op=True)
+        self._pending = (b, work, i)
+
+    def result(self) -> torch.Tensor:
+        assert self._pending is not None, "result() without submit()"
+        if self.world == 1:
+            b, _ = self._pending
+            self._pending = None
+            return b
+        b, work, i = self._pending
+        self._pending = None
+        work.wait()  # NCCL: the CURRENT stream waits for the collective; gloo: the host does
+        self._last = i
+        return b
+
+    def consumed(self) -> None:
+        if self.world == 1 or not self.cuda or self._last is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._free[self._last] = ev
 
 
 class ShardedReceiver:

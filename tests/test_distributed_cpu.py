@@ -42,6 +42,19 @@ def _worker(rank, world, port, q):
         frame = torch.from_numpy(synth.lcg_frame(topo.frame, lcg)) if rank == 0 else None
         local = sr.process(frame)
         res.append((float(local.double().sum()), {k: v.copy() for k, v in sr.engine.outputs().items()}))
+    # the overlapped form the bench uses: the broadcast of frame k+1 is in flight while frame k is processed
+    bc = D.FrameBroadcast(topo.frame, torch.device("cpu"))
+    lcg2 = synth.Lcg(7)
+    sums = []
+    bc.submit(torch.from_numpy(synth.lcg_frame(topo.frame, lcg2)) if rank == 0 else None)
+    for f in range(4):
+        b = bc.result()
+        sums.append(float(b.double().sum()))  # "processing" frame f ...
+        bc.consumed()
+        bc.submit(torch.from_numpy(synth.lcg_frame(topo.frame, lcg2)) if rank == 0 else None)  # ... while f+1 travels
+    bc.result()
+    want = synth.Lcg(7)
+    assert sums == [float(synth.lcg_frame(topo.frame, want).astype(np.float64).sum()) for _ in range(4)], sums
     # weak-scaling bookkeeping the bench uses: totals are sums over ranks
     t = torch.tensor([float(sr.topo.vfo_samples_per_frame())], dtype=torch.float64)
     dist.all_reduce(t)
