@@ -11,8 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.gpu
-def test_two_ranks_share_one_gpu():
+def _launch():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -30,5 +29,16 @@ def test_two_ranks_share_one_gpu():
                 q.kill()
             raise
         outs.append(out)
-    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return all(p.returncode == 0 for p in procs), outs
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu():
+    # one retry: the rendezvous port is picked by bind-and-release, and on a fresh box this may be the
+    # first two processes to initialise the GPU at the same moment
+    ok, outs = _launch()
+    if not ok:
+        print("first attempt failed:\n" + "\n".join(outs))
+        ok, outs = _launch()
+    assert ok, "\n".join(outs)
     assert "OK 27 leaves over 2 ranks" in outs[0], outs[0]
