@@ -92,6 +92,26 @@ def test_cpp_missing_profile_is_an_error(tmp_path):
     assert r.returncode == 1 and "doesn't exist" in r.stderr
 
 
+def test_header_is_plain_c_and_fails_loudly_without_a_gpu():
+    """host/abi_check.c: gcc -std=c99 -pedantic -Werror over include/sdrx.h, linked to libsdrx.so.
+    On a box without a GPU sdrx_create must refuse (no CPU fallback); on the GPU box the same
+    program pushes a frame through the VFO01 chain (test below)."""
+    import torch
+    _build()
+    r = subprocess.run([os.path.join(ROOT, "host", "abi_check")], capture_output=True, text=True)
+    assert "sdrx ABI version 1, sizeof(sdrx_vfo_desc) = 56" in r.stdout
+    if not torch.cuda.is_available():
+        assert r.returncode == 3 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c99_program_over_the_abi():
+    _build()
+    r = subprocess.run([os.path.join(ROOT, "host", "abi_check")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "published VFO01 rate 12000 bytes 6000" in r.stdout
+
+
 def _fnv1a(b: bytes) -> int:
     h = 1469598103934665603
     for x in b:
