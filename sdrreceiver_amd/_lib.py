@@ -90,6 +90,15 @@ def lib() -> C.CDLL:
             raise ImportError(f"{LIB_PATH} is missing: the HIP extension must be built "
                               f"(python -c 'import __graft_entry__ as g; g.build()' or make -C {CSRC}); "
                               "there is no CPU fallback")
+        # PyTorch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1 -- the same
+        # SONAMEs as /opt/rocm's, so whichever copy a process loads first serves everything in it.
+        # libsdrx.so runs on either; torch cannot initialise on top of the newer system runtime
+        # ("no ROCm-capable device is detected").  So when torch is installed it loads its copy
+        # first, and a process may use the library and torch in any order afterwards.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)  # AttributeError if the header and the library ever diverge
