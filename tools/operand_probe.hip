@@ -20,6 +20,34 @@ __global__ __launch_bounds__(64) void k(float *out, int iters, float a)
                 if (MODE == 6) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "v"(tv), "v"(tv));
                 if (MODE == 7) asm volatile("v_mul_f32 %0, 0.5, %0" : "+v"(v[i]));
             }
+        // packed forms on register pairs (two results per instruction)
+        if (MODE >= 8) {
+            typedef float v2 __attribute__((ext_vector_type(2)));
+            v2 p[4], t2 = {tv, tv * 1.5f}, acc[4];
+            for (int i = 0; i < 4; ++i) p[i] = v2{v[2 * i], v[2 * i + 1]}, acc[i] = v2{0.f, 0.f};
+            const unsigned long long spair = ((unsigned long long)__float_as_uint(a) << 32) | __float_as_uint(a * 0.5f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (MODE == 8) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(t2));
+                    if (MODE == 9) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(p[i]) : "s"(spair));
+                    if (MODE == 10) asm volatile("v_pk_mul_f32 %0, %1, %0 op_sel:[1,0] op_sel_hi:[0,0]" : "+v"(p[i]) : "s"(spair));
+                    if (MODE == 11) { // exact MAC pair: pk_mul (sgpr pair x broadcast vgpr) + pk_add
+                        v2 m;
+                        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0]" : "=v"(m) : "s"(spair), "v"(p[i]));
+                        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(m));
+                    }
+                    if (MODE == 12) { // the same two MACs with scalar ops: 2 x (v_mul sgpr + v_add)
+                        float m0, m1;
+                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m0) : "s"(a), "v"(p[i].x));
+                        asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[i].x) : "v"(m0));
+                        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m1) : "s"(a), "v"(p[i].x));
+                        asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[i].y) : "v"(m1));
+                    }
+                }
+            for (int i = 0; i < 4; ++i) v[2 * i] = p[i].x + acc[i].x, v[2 * i + 1] = p[i].y + acc[i].y;
+        }
     }
     float s = 0;
     for (int i = 0; i < 8; ++i) s += v[i];
@@ -52,5 +80,10 @@ int main()
         run<4>("v_fma vgpr x3", w);
         run<5>("v_fma vgpr,sgpr,vgpr", w);
         run<6>("v_fmac vgpr", w);
+        run<8>("v_pk_mul vgpr pairs", w);
+        run<9>("v_pk_mul sgpr pair,vgpr", w);
+        run<10>("v_pk_mul sgpr pair op_sel", w);
+        run<11>("MAC pair: pk_mul s + pk_add (per 64 ops)", w);
+        run<12>("MAC pair: 2x(v_mul s + v_add) (per 64 ops)", w);
     }
 }
