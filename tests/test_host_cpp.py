@@ -86,6 +86,26 @@ def test_cpp_ini_front_door_on_shipped_profiles(tmp_path):
         _check_dump(_dump(text, tmp_path), tp.topology_from_ini(text))
 
 
+def test_cpp_ini_front_door_under_sanitizers(tmp_path):
+    """host/sdrx_host.hpp's parser and tree builder under ASan + UBSan (leak check on), on the INIs of
+    this file and -- where present -- every shipped sample profile."""
+    exe = tmp_path / "demo_san"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", str(exe),
+                           os.path.join(ROOT, "host", "demo.cpp"), "-L" + os.path.join(ROOT, "sdrreceiver_amd"), "-lsdrx",
+                           "-Wl,-rpath," + os.path.join(ROOT, "sdrreceiver_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    inis = []
+    for k, text in enumerate([INI_25E_LIKE, INI_54W_LIKE]):
+        p = tmp_path / f"p{k}.ini"
+        p.write_text(text)
+        inis.append(str(p))
+    d = os.path.join(REFERENCE_ROOT, "sample_ini")
+    if os.path.isdir(d):
+        inis += [os.path.join(d, n) for n in sorted(os.listdir(d))]
+    for ini in inis:
+        r = subprocess.run([str(exe), ini, "--dump"], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+        assert r.returncode == 0 and r.stderr == "", (ini, r.stderr[-1500:])
+
+
 def test_cpp_missing_profile_is_an_error(tmp_path):
     _build()
     r = subprocess.run([DEMO, str(tmp_path / "nope.ini"), "--dump"], capture_output=True, text=True)
