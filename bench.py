@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the per-VFO IQ chain on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3|flat|config2|config4|config5|10k|64k]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3|flat|config2|config4|config5|10k|64k|256k]
                     [--fast] [--no-cpu]
 
 A "step" is one pass of the hot path over one raw IQ frame (250 ms of signal: 384 000 cf32 at
@@ -46,6 +46,8 @@ def make_topology(name, world):
         return tp.config3(10240 * world), "north-star target: 10 240 sub VFOs per GPU under the 2 sdr_25E mains"
     if name == "config5":
         return tp.config5(65536), "BASELINE config 5: 65 536 sub VFOs in total, sharded over the GPUs (strong scaling), raw frame broadcast"
+    if name == "256k":
+        return tp.config3(262144 * world), "memory-scale check: 262 144 sub VFOs per GPU under the 2 sdr_25E mains (~70 GB of HBM)"
     if name == "64k":
         return tp.config3(65536 * world), "BASELINE config 5's tree on ONE GPU: 65 536 sub VFOs under the 2 sdr_25E mains"
     raise SystemExit(f"unknown workload {name}")
