@@ -258,6 +258,28 @@ def main():
                          "frame_frac": round(alg_bytes / world / (frame_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kernels,
         }
+        if world == 1 and args.workload == "config3":
+            # BASELINE.json configs[1] (32 sub VFOs), the same way, as a side reading: a latency-bound
+            # plumbing case on this hardware (three ~10 us launches per frame)
+            try:
+                t2 = tp.config2()
+                rx2 = Receiver.from_topology(t2, device=local, exact=not args.fast)
+                rx2.set_stream(stream.cuda_stream)
+                st2 = rx2.stats()
+                for _ in range(args.warmup):
+                    rx2.process_device(src.data_ptr(), t2.frame)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    rx2.process_device(src.data_ptr(), t2.frame)
+                torch.cuda.synchronize()
+                d2 = (time.perf_counter() - t0) / args.steps
+                rx2.close()
+                out["configs1_32_sub_vfos"] = {"ms_per_step": round(d2 * 1e3, 4), "value": round(st2["vfo_samples_per_frame"] / d2 / 1e6, 2),
+                                               "unit": "MSamples/s", "realtime_factor": round(frame_seconds / d2, 1),
+                                               "algorithmic_GBps_whole_frame": round(st2["algorithmic_bytes_per_frame"] / d2 / 1e9, 1)}
+            except Exception as e:
+                out["configs1_32_sub_vfos"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload)
