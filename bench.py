@@ -206,6 +206,16 @@ def main():
         rx.fetch()
     barrier()
     dt_d2h = (time.perf_counter() - t1) / min(args.steps, 10)
+    # fourth: the same without the (Python, ctypes) callbacks -- what a C / C++ host sees: kernels + payload D2H
+    rx.set_publish(False)
+    barrier()
+    t1 = time.perf_counter()
+    for k in range(min(args.steps, 10)):
+        step(k)
+        rx.fetch()
+    barrier()
+    dt_d2h_nocb = (time.perf_counter() - t1) / min(args.steps, 10)
+    rx.set_publish(True)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -251,6 +261,7 @@ def main():
             "realtime_factor": round(frame_seconds / (dt / args.steps), 1),
             "algorithmic_GBps_whole_frame": round(args.steps * alg_bytes / dt / 1e9, 1),
             "ms_per_step_with_payload_d2h_and_callbacks": round(dt_d2h * 1e3, 4),
+            "ms_per_step_with_payload_d2h": round(dt_d2h_nocb * 1e3, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 5),

@@ -55,6 +55,11 @@ class Receiver:
     def _on_publish(self, user, topic, rate, buf, length):
         self.published.append((C.string_at(topic, 5), int(rate), C.string_at(buf, length)))
 
+    def set_publish(self, enabled: bool) -> None:
+        """Install / remove the per-leaf publish callback (a ctypes callback costs microseconds per
+        leaf: a C or C++ host pays nanoseconds)."""
+        self._chk(self.L.sdrx_set_publish_callback(self.h, self._cb if enabled else _lib.PUBLISH_FN(0), None))
+
     def close(self):
         if getattr(self, "h", None):
             self.L.sdrx_destroy(self.h)
