@@ -610,12 +610,13 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
                     *reinterpret_cast<v4f *>(lds + pad0(lane * kRun + 2 * i)) = cat2(x[2 * i], x[2 * i + 1]);
                 wave_sync();
                 if (emit) {
+                    // pad0(128 i + 2 lane) = 144 i + pad0(2 lane): one base address, constant offsets
+                    const v2f *src = lds + pad0(2 * lane);
+                    float2 *dst = out + base + 2 * lane;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int u = i * 64 + lane;
-                        if (2 * u < valid)
-                            gstv4(reinterpret_cast<float4 *>(out + base + 2 * u), *reinterpret_cast<const v4f *>(lds + pad0(2 * u)));
-                    }
+                    for (int i = 0; i < 8; ++i)
+                        if (128 * i + 2 * lane < valid)
+                            gstv4(reinterpret_cast<float4 *>(dst + 128 * i), *reinterpret_cast<const v4f *>(src + 144 * i));
                 }
             }
             continue;
