@@ -2,7 +2,7 @@
 """bench.py -- throughput of the per-VFO IQ chain on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3|flat|config2|config4|config5|10k|64k|256k]
-                    [--fast] [--no-cpu]
+                    [--fast] [--no-cpu] [--configs1]
 
 A "step" is one pass of the hot path over one raw IQ frame (250 ms of signal: 384 000 cf32 at
 1.536 MS/s), already resident in HBM, through every VFO of the workload.  Default workload =
@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--fast", action="store_true", help="FMA arithmetic (within 1e-6 of the reference) instead of bit-exact")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--segments", type=int, default=0)
+    ap.add_argument("--configs1", action="store_true",
+                    help="also time BASELINE configs[1] (32 sub VFOs) and report it as a side reading (off by default: the "
+                         "profiled default command must launch the kernels of ONE workload only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -269,7 +272,7 @@ def main():
                          "frame_frac": round(alg_bytes / world / (frame_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kernels,
         }
-        if world == 1 and args.workload == "config3":
+        if world == 1 and args.configs1:
             # BASELINE.json configs[1] (32 sub VFOs), the same way, as a side reading: a latency-bound
             # plumbing case on this hardware (three ~10 us launches per frame)
             try:
