@@ -300,6 +300,8 @@ def main():
             except Exception as e:  # the bench line must still come out
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
+    bcast.result()  # drain the broadcast that is still in flight before the process group goes away
+    barrier()
     rx.close()
     if world > 1:
         dist.destroy_process_group()
