@@ -160,9 +160,22 @@ def main():
 
     # The broadcast of frame k+1 (RCCL, its own stream) overlaps the processing of frame k; at N = 1
     # submit/result hand the resident frame straight through.
-    bcast.submit(src)
+    overlap = True
+    try:
+        bcast.submit(src)
+        bcast.result()
+        bcast.consumed()
+        bcast.submit(src)
+    except Exception as e:  # fall back to the serial broadcast rather than lose the run
+        overlap = False
+        if rank == 0:
+            print(f"bench: overlapped broadcast unavailable ({type(e).__name__}: {e}); broadcasting in line", file=sys.stderr)
 
     def step(k):
+        if not overlap:
+            b = bcast(src)
+            rx.process_device(b.data_ptr(), topo.frame)
+            return
         b = bcast.result()
         rx.process_device(b.data_ptr(), topo.frame)
         bcast.consumed()
@@ -300,7 +313,8 @@ def main():
             except Exception as e:  # the bench line must still come out
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
-    bcast.result()  # drain the broadcast that is still in flight before the process group goes away
+    if overlap:
+        bcast.result()  # drain the broadcast that is still in flight before the process group goes away
     barrier()
     rx.close()
     if world > 1:
