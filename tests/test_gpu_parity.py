@@ -513,6 +513,21 @@ def test_random_trees_against_the_oracle(Receiver):
     assert ran >= 55, ran
 
 
+def test_long_run_wraps_the_nco_tables_many_times(Receiver):
+    """40 frames = 10 s of signal through config 1: every NCO table (1 s long) wraps ten times, the
+    frame parity of every ping-pong buffer flips forty times; still bit-identical at the end and at
+    every fifth frame on the way."""
+    topo = tp.config1()
+    rx = Receiver.from_topology(topo, exact=True)
+    nodes, roots = ob.build_tree("port", topo)
+    for f, iq in _frames(topo, 40, seed=31, tones=[(485000.0, 40.0)]):
+        rx.process(iq)
+        ob.process_roots(roots, iq)
+        if f % 5 == 4:
+            _check_exact(rx, nodes, topo, ("long", f))
+    rx.close()
+
+
 def test_three_level_tree(Receiver):
     """vfo::process recurses (vfo.cpp:253-264); the reference only builds two levels, the library
     takes any depth: raw -> d=2 -> d=1 -> {d=2 USB leaf with low-pass, d=0 USB leaf, d=3 IQ leaf}."""
