@@ -834,7 +834,7 @@ __host__ __device__ constexpr int late4_pad(int R, int L) { return (2 * R * L) %
 __host__ __device__ constexpr int late4_lds_bytes(int R, int L, int ndec) // for the launch's largest L and Nd
 {
     const int span = L * (64 * R - 1) + ndec + (R - 1) * L;
-    return 4 * R * kLateTapRow + 8 * (span + 2 * (span / (R * L)) + 8);
+    return 4 * R * kLateTapRow + 8 * (span + 2 * (span / (R * L)) + 16);
 }
 
 template <bool EXACT, int L, int R>
@@ -843,7 +843,7 @@ __device__ __forceinline__ void late4_body(const float2 *__restrict__ x, float2 
 {
     constexpr int kPad = late4_pad(R, L);
     constexpr int kStride = R * L + kPad;                                          // float2 per lane
-    constexpr int kIters = (L * (64 * R - 1) + kLateMaxTaps + (R - 1) * L + 63) / 64; // window loads per lane
+    constexpr int kIters = (L * (64 * R - 1) + kLateMaxTaps + (R - 1) * L + 8 + 63) / 64; // window loads per lane (+8: zero tail)
     constexpr int kTapIters = (R * kLateTapRow + 63) / 64;
     const int lo = L * k0 - ndec;                       // first input index of the tile's window (>= -Hx)
     const int span = L * (64 * R - 1) + ndec + (R - 1) * L; // lanes' windows end at lo + R L lane + ndec + (R-1) L
@@ -865,7 +865,7 @@ __device__ __forceinline__ void late4_body(const float2 *__restrict__ x, float2 
 #pragma unroll
     for (int it = 0; it < kIters; ++it) {
         const int t = lane + 64 * it;
-        if (t < span)
+        if (t < span + 8) // the entries just past the span are read under zero taps only: they must be finite
             sx[t + kPad * (t / (R * L))] = stage[it];
     }
 #pragma unroll
@@ -1066,6 +1066,8 @@ __global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfo
                 sU[t + soff] = (float)((double)sI[t] - (double)acc[rr]);
         }
     }
+    if (tid < 16) // read by the low-pass only under its zero padding taps: must be finite (0 * NaN = NaN)
+        sU[ntv + soff + tid] = 0.f;
     __syncthreads();
 
     // ---- audio low-pass (newest sample excluded) on 4 consecutive outputs, then int16
