@@ -1066,8 +1066,8 @@ __global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfo
                 sU[t + soff] = (float)((double)sI[t] - (double)acc[rr]);
         }
     }
-    if (tid < 16) // read by the low-pass only under its zero padding taps: must be finite (0 * NaN = NaN)
-        sU[ntv + soff + tid] = 0.f;
+    if (tid < 8) // read by the low-pass only under its zero padding taps: must be finite (0 * NaN = NaN)
+        sU[ntv + soff + tid] = 0.f; // <= 1280 + 3 + 7, inside sU
     __syncthreads();
 
     // ---- audio low-pass (newest sample excluded) on 4 consecutive outputs, then int16
