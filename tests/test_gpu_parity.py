@@ -528,6 +528,31 @@ def test_long_run_wraps_the_nco_tables_many_times(Receiver):
     rx.close()
 
 
+def test_longest_audio_filters(Receiver):
+    """The audio low-pass at the top of the supported range: 255 taps (48 k, bw 1817), 251 (bw 1850),
+    155 (bw 3000, the 3 kHz case SURVEY lists) and 31 (bw 15000), odd and even history lengths, also
+    behind the /5 late decimation; 4 frames so the 124 + N samples of history span a frame boundary."""
+    t = tp.Topology(fs=1536000, frame=384000, name="longfir")
+    t.vfos.append(tp.VfoDesc(parent=-1, fs=1536000, decimate_count=3, mixer_freq=-496000.0, demod_usb=False, cstyle=1,
+                             samples_per_buffer=384000))
+    for k, bw in enumerate([1817, 1850, 3000, 15000, 2000]):
+        t.vfos.append(tp.VfoDesc(topic=f"F{k}", parent=0, fs=192000, decimate_count=2, mixer_freq=float(-41300 + 7000 * k),
+                                 filter_bw=bw, gain=tp._g(0.05), cstyle=1, samples_per_buffer=48000))
+    t.vfos.append(tp.VfoDesc(parent=-1, fs=1536000, decimate_count=0, mixer_freq=100000.0, demod_usb=False, cstyle=1,
+                             samples_per_buffer=384000))
+    t.vfos.append(tp.VfoDesc(topic="L5", parent=len(t.vfos) - 1, fs=1536000, decimate_count=3, mixer_freq=-30000.0, late_decimate=6,
+                             filter_bw=1300, gain=tp._g(0.04), cstyle=1, samples_per_buffer=384000))
+    rx = Receiver.from_topology(t, exact=True)
+    nodes, roots = ob.build_tree("port", t)
+    lens = [len(rx.taps(i, "fir_usb")) for i in range(1, 6)]
+    assert lens == [255, 251, 155, 31, 231], lens
+    for f, iq in _frames(t, 4, seed=17, tones=[(-496000.0 - 40000.0, 30.0)]):
+        rx.process(iq)
+        ob.process_roots(roots, iq)
+        _check_exact(rx, nodes, t, ("longfir", f))
+    rx.close()
+
+
 def test_three_level_tree(Receiver):
     """vfo::process recurses (vfo.cpp:253-264); the reference only builds two levels, the library
     takes any depth: raw -> d=2 -> d=1 -> {d=2 USB leaf with low-pass, d=0 USB leaf, d=3 IQ leaf}."""
