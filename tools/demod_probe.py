@@ -1,5 +1,5 @@
 """k_usb_demod time by VFO kind: 1024 d=2 subs (192 k -> 48 k), all with / all without the 10 kHz low-pass."""
-import copy, json, os, sys
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sdrreceiver_amd import topology as tp
 from class_probe import run, only

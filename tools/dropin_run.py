@@ -18,7 +18,6 @@ sys.path.insert(0, ROOT)
 
 
 def fnv1a(b: bytes) -> int:
-    import numpy as np  # vectorised: h = (h ^ x) * p is sequential, so plain loop in chunks via int arithmetic
     h = 1469598103934665603
     for x in b:
         h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
