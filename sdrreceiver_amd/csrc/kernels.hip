@@ -430,7 +430,11 @@ __device__ __forceinline__ void hb_stage_lds(v2f *__restrict__ A, v2f *__restric
     wave_sync(); // stage input (written by the previous phase) is visible
     const int nout = cnt >> 1;
     for (int j = lane; j < nout; j += 64) {
+#ifndef SDRX_ABL_CONFLICT
         const v2f *w = A + kCarry + 2 * j - 10; // w[0..10], newest = input sample 2j of this chunk
+#else
+        const v2f *w = A + kCarry + j - 10 + (j >> 6); // ablation: lane stride 1 (conflict-free reads, wrong results)
+#endif
         const v2f y = hb_dot2<EXACT>(w[0], w[2], w[4], w[5], w[6], w[8], w[10]);
         if (!last)
             B[kCarry + j] = y;
