@@ -694,6 +694,17 @@ int sdrx_finalize(sdrx_ctx *c)
         ow2a = plan.take(sizeof(BlockWork) * w2a.size());
         c->lb.push_back({KIND_LATE_DEC, (int)w2a.size(), o2a, ow2a, c->late4 ? late4_lds_bytes(c->late4_r, late_lmax, late_ndec) : lds2a, b2a});
     }
+    if (!d2.empty() && !getenv("SDRX_NO_LPT")) {
+        // Blocks are independent and the launch is a few resident rounds deep, so its tail is set by
+        // what is dispatched last: longest blocks first (a block with the audio low-pass does about
+        // twice the work; the last block of a VFO-frame may be nearly empty).
+        auto cost = [&](const BlockWork &b) {
+            const Node &n = c->nodes[(size_t)n2[(size_t)b.vfo]];
+            const int outs = std::min(kDemodTile, n.n_out - b.blk * kDemodTile);
+            return (long long)outs * (kHilbertNz + (long long)n.lpf.size());
+        };
+        std::stable_sort(w2.begin(), w2.end(), [&](const BlockWork &a, const BlockWork &b) { return cost(a) > cost(b); });
+    }
     if (!d2.empty()) {
         o2 = plan.take(sizeof(K2Vfo) * d2.size());
         ow2 = plan.take(sizeof(BlockWork) * w2.size());
