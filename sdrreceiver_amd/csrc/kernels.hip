@@ -988,11 +988,11 @@ __global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfo
         short *pay;
         float *prequant;
         float gain;
-        int H, n, nlpf;
-    } D = {Dp->hnz, Dp->lpf_pad, Dp->pay, Dp->prequant, Dp->gain, Dp->H, Dp->n, Dp->nlpf};
+        int H, n, nlpf, tile;
+    } D = {Dp->hnz, Dp->lpf_pad, Dp->pay, Dp->prequant, Dp->gain, Dp->H, Dp->n, Dp->nlpf, Dp->tile};
     const float2 *sbase = Dp->s[par];
     float2 *snext = Dp->s_next[par];
-    const int m0 = blk * kDemodTile;
+    const int m0 = blk * D.tile;
     if (m0 >= D.n && blk != 0)
         return;
     // The 62 Hilbert taps, read before this kernel has stored anything so the compiler can use
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfo
     const float2 *z = sbase + D.H; // sample 0 of this frame
     const int N = D.nlpf;
     const int E = N + (N & 1);                  // usb values m0-E .. m0+1023 are computed (t = 0 .. ntv-1)
-    const int ntv = kDemodTile + E;
+    const int ntv = D.tile + E;                 // <= 1024 when the host shortens the tile of a low-pass VFO by E: one usb pass
     const int lo = m0 - E - (kHilbert - 1);     // first stream index touched (>= -H)
     const int nr = ntv + (kHilbert - 1);        // offsets r = idx - lo in [0, nr)
     // all of this thread's loads are issued before the first LDS write (a rolled load -> wait ->
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfo
     // ---- audio low-pass (newest sample excluded) on 4 consecutive outputs, then int16
     const int j0 = 4 * tid;
     const int m = m0 + j0;
-    if (m >= D.n)
+    if (j0 >= D.tile || m >= D.n)
         return;
     float u4[4];
     if (N > 0) {

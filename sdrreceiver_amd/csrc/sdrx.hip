@@ -52,6 +52,7 @@ struct Node {
     // designed taps (host copies for sdrx_get_taps)
     std::vector<float> lpf, dec, hilbert;
     std::vector<float> lpf_pad, hnz; // device forms: zero-padded low-pass, compacted Hilbert
+    int demod_tile = 1024;           // outputs per k_usb_demod block
     // device placement (byte offsets into the arena)
     size_t off_cp = 0, off_hb[2] = {0, 0}, off_stream[2] = {0, 0}, off_z[2] = {0, 0}, off_preq = 0;
     size_t off_lpf = 0, off_dec = 0, off_hilbert = 0, off_hnz = 0;
@@ -674,7 +675,14 @@ int sdrx_finalize(sdrx_ctx *c)
                 d2a.push_back(K2aVfo{});
                 lds2a = std::max(lds2a, (int)sizeof(float2) * (n.d.late_decimate * 255 + (int)n.dec.size()));
             }
-            for (int b = 0; b < (n.n_out + kDemodTile - 1) / kDemodTile; ++b)
+            {
+                // a block computes E = nlpf (rounded up to even) extra usb values as history for its low-pass:
+                // its tile is shortened by E so that usb stays ONE pass of <= 1024 values (a second pass would
+                // keep two of the four waves busy for a whole Hilbert loop on ~50 values)
+                const int nl = (int)n.lpf.size();
+                n.demod_tile = (nl > 0 && !getenv("SDRX_DEMOD_FULL_TILE")) ? ((kDemodTile - (nl + (nl & 1))) & ~3) : kDemodTile;
+            }
+            for (int b = 0; b < (n.n_out + n.demod_tile - 1) / n.demod_tile; ++b)
                 w2.push_back({(int)d2.size(), b});
             n2.push_back(i);
             d2.push_back(K2Vfo{});
@@ -700,7 +708,7 @@ int sdrx_finalize(sdrx_ctx *c)
         // twice the work; the last block of a VFO-frame may be nearly empty).
         auto cost = [&](const BlockWork &b) {
             const Node &n = c->nodes[(size_t)n2[(size_t)b.vfo]];
-            const int outs = std::min(kDemodTile, n.n_out - b.blk * kDemodTile);
+            const int outs = std::min(n.demod_tile, n.n_out - b.blk * n.demod_tile);
             return (long long)outs * (kHilbertNz + (long long)n.lpf.size());
         };
         std::stable_sort(w2.begin(), w2.end(), [&](const BlockWork &a, const BlockWork &b) { return cost(a) > cost(b); });
@@ -790,6 +798,7 @@ int sdrx_finalize(sdrx_ctx *c)
         k.H = late ? n.H : n.Hx;
         k.n = n.n_out;
         k.nlpf = (int)n.lpf.size();
+        k.tile = n.demod_tile;
     }
     for (size_t q = 0; q < d3.size(); ++q) {
         Node &n = c->nodes[(size_t)n3[q]];

@@ -66,6 +66,8 @@ struct K2Vfo {
     float *prequant;        // optional n floats
     float gain;
     int H, n, nlpf;
+    int tile;               // outputs per block: 1024, or 1024 - E with the low-pass (E = nlpf rounded up to even)
+    int pad_;
 };
 
 // ---- compress() for childless non-USB VFOs (vfo.cpp:389-424) ----------------------------------
