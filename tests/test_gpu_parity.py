@@ -553,6 +553,29 @@ def test_longest_audio_filters(Receiver):
     rx.close()
 
 
+def test_contexts_do_not_leak_device_memory(Receiver):
+    """30 receivers created, run for a frame and destroyed (mainwindow's stop/start cycle): device
+    memory in use returns to where it was (hipFree of every arena, staging buffer, stream, event)."""
+    import torch
+    topo = golden_topology("profile_25e")
+    iq = synth.lcg_frame(topo.frame, synth.Lcg(2))
+
+    def cycle():
+        rx = Receiver.from_topology(topo)
+        rx.process(iq)
+        rx.process_u8((iq + 127).astype(np.uint8), correct_dc=True)
+        rx.close()
+
+    cycle()  # one-time allocations of the runtime (code objects, scratch) happen here
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(30):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, (free0, free1)  # a context of this profile holds ~30 MB: 30 leaked ones would show
+
+
 def test_three_level_tree(Receiver):
     """vfo::process recurses (vfo.cpp:253-264); the reference only builds two levels, the library
     takes any depth: raw -> d=2 -> d=1 -> {d=2 USB leaf with low-pass, d=0 USB leaf, d=3 IQ leaf}."""
