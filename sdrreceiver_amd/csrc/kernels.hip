@@ -424,7 +424,7 @@ __device__ __forceinline__ void wave_sync()
 // the output stream when this is the last stage.
 template <bool EXACT>
 __device__ __forceinline__ void hb_stage_lds(v2f *__restrict__ A, v2f *__restrict__ B, float2 *__restrict__ gout, int gbase,
-                                             bool tiled, bool last, bool emit, int cnt, int lane, bool save,
+                                             bool tiled, bool last, int jmin, int cnt, int lane, bool save,
                                              float2 *__restrict__ hbsave)
 {
     wave_sync(); // stage input (written by the previous phase) is visible
@@ -438,7 +438,7 @@ __device__ __forceinline__ void hb_stage_lds(v2f *__restrict__ A, v2f *__restric
         const v2f y = hb_dot2<EXACT>(w[0], w[2], w[4], w[5], w[6], w[8], w[10]);
         if (!last)
             B[kCarry + j] = y;
-        else if (emit)
+        else if (j >= jmin) // outputs below jmin belong to the warm-up of a segment that starts inside the frame
             gstv2(gout + (tiled ? tile_pos(gbase + j) : (size_t)(gbase + j)), y);
     }
     wave_sync(); // all window reads done before the carry is overwritten
@@ -495,8 +495,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
     float2 *out = Dp->out[par];
     const float2 *hb_load = Dp->hb[par];
     float2 *hb_save = Dp->hb[par ^ 1];
-    const int nchunks = (D.n_in + kChunk - 1) / kChunk;
-    const bool from_state = W.c_begin == 0;
+    const bool from_state = W.s_begin == 0;
     const v2f zero2 = {0.f, 0.f};
 
     // Filter state at the start of this segment: segment 0 continues from the previous frame's
@@ -514,15 +513,21 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
         }
     const int phase_frame = (int)((frame_no * (unsigned long long)D.n_in) % (unsigned long long)D.L);
 
-    for (int c = W.c_begin; c < W.c_end; ++c) {
-        const int base = c * kChunk;
-        const int valid = min(kChunk, D.n_in - base);
+    // The item walks 1024-sample chunks from sample s_begin (any multiple of 16: a chunk need not
+    // coincide with a tile of the input) and emits the outputs whose input position is >= s_first_out.
 #ifndef SDRX_ABL_STORE
-        const bool emit = c >= W.c_first_out;
+    const int first_out = W.s_first_out;
 #else
-        const bool emit = c >= W.c_first_out && D.n_in == 12345; // ablation: never true at run time
+    const int first_out = D.n_in == 12345 ? W.s_first_out : 0x7fffffff; // ablation: nothing is ever emitted
 #endif
-        const bool save = c == nchunks - 1 && W.c_end == nchunks;
+    const bool aligned = (W.s_begin & (kChunk - 1)) == 0; // wave-uniform
+    for (int base = W.s_begin; base < W.s_end; base += kChunk) {
+        const int valid = min(kChunk, D.n_in - base);
+        const int p16 = (base >> 4) + lane;               // this lane's run, in units of 16 samples
+        const int p16c = min(p16, (D.n_in >> 4) - 1);     // ... clamped into the frame, for addressing the input
+        const bool emit = base + kChunk > first_out;      // the chunk reaches into the emitted range
+        const bool emit_l = (p16 << 4) >= first_out;      // ... and this lane's run lies inside it
+        const bool save = base + valid == D.n_in;         // the chunk that holds the frame's last sample
         const int lv = (valid >> 4) - 1; // last lane holding real samples
         const bool active = lane <= lv;
 
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
             // the caller's frame as it is (natural order): each lane reads its own 128 contiguous
             // bytes.  Uncoalesced across the wave, but a level of 2-3 main VFOs is latency bound
             // and this saves the layout pass over the raw frame.
-            const float4 *nat = reinterpret_cast<const float4 *>(raw) + (size_t)c * 512 + lane * 8;
+            const float4 *nat = reinterpret_cast<const float4 *>(raw) + (size_t)p16 * 8;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const v4f z4 = {0.f, 0.f, 0.f, 0.f};
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
             }
         } else if (LEVEL == 0 && raw_mode == kRawU8) {
             // dongle bytes: floats[b] = b - 127 (jonti/sdr.cpp:43-49), 32 bytes per lane
-            const v4u *nat = reinterpret_cast<const v4u *>(raw) + (size_t)c * 128 + lane * 2;
+            const v4u *nat = reinterpret_cast<const v4u *>(raw) + (size_t)p16 * 2;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const v4u z4 = {0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu}; // 127 -> 0.0f
@@ -558,12 +563,17 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
                 }
             }
         } else {
+            // An item whose walk is tile aligned addresses its chunk uniformly (scalar tile base + lane);
+            // a shifted walk straddles two tiles: per-lane tile and position.  Lanes past the frame's
+            // end re-read the last real run: their own tile may not exist, and nothing they compute
+            // is stored or reaches a lane that is.
+            const float4 *src = aligned ? in + tile_unit(base >> 10, 0, lane) : in + tile_unit(p16c >> 6, 0, p16c & 63);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #ifndef SDRX_ABL_LOAD
-                const v4f v = gldv4(in + tile_unit(c, i, lane));
+                const v4f v = gldv4(src + 64 * i); // tile_unit(c, i, l) = tile_unit(c, 0, l) + 64 i
 #else
-                v4f v = {1.f * lane, 2.f, 3.f * c, 4.f * i}; // ablation: no global loads
+                v4f v = {1.f * lane, 2.f, 3.f * base, 4.f * i}; // ablation: no global loads
                 asm volatile("" : "+v"(v));
 #endif
                 x[2 * i] = lo2(v);
@@ -600,11 +610,11 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
         if (D.d == 0) {
             // no decimation: decimate[0] is the mixed stream itself
             if (D.out_tiled) {
-                if (emit && active) {
+                if (emit_l && active) {
                     float4 *o4 = reinterpret_cast<float4 *>(out);
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        gstv4(o4 + tile_unit(c, i, lane), cat2(x[2 * i], x[2 * i + 1]));
+                        gstv4(o4 + tile_unit(p16 >> 6, i, p16 & 63), cat2(x[2 * i], x[2 * i + 1]));
                 }
             } else {
                 // natural order wanted: transpose through LDS so the stores are coalesced
@@ -619,7 +629,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
                     float2 *dst = out + base + 2 * lane;
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        if (128 * i + 2 * lane < valid)
+                        if (128 * i + 2 * lane < valid && base + 128 * i + 2 * lane >= first_out)
                             gstv4(reinterpret_cast<float4 *>(dst + 128 * i), *reinterpret_cast<const v4f *>(src + 144 * i));
                 }
             }
@@ -669,7 +679,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
                 gstv2(hb_save + 0 * kHbHist + k - 1, x[15 - k]);
 
         if (D.d == 1) {
-            if (emit && active) {
+            if (emit_l && active) {
                 const int g = (base >> 1) + lane * 8;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -729,7 +739,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
 #endif
 
         if (D.d == 2) {
-            if (emit && active) {
+            if (emit_l && active) {
                 const int g = (base >> 2) + lane * 4;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -752,8 +762,8 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
         continue;
 #endif
         for (int s = kRegStages; s < D.d; ++s)
-            hb_stage_lds<EXACT>(lds + stage_offset(s), lds + stage_offset(s + 1), out, base >> D.d, D.out_tiled != 0, s + 1 == D.d, emit,
-                                valid >> s, lane, save, hb_save + s * kHbHist);
+            hb_stage_lds<EXACT>(lds + stage_offset(s), lds + stage_offset(s + 1), out, base >> D.d, D.out_tiled != 0, s + 1 == D.d,
+                                max(0, (first_out - base) >> D.d), valid >> s, lane, save, hb_save + s * kHbHist);
     }
 }
 

@@ -165,14 +165,20 @@ struct ArenaPlan {
     }
 };
 
-int warmup_chunks(int d)
+// A segment that starts inside the frame starts from zero filter state.  An output of stage d with
+// index j (counted from the segment's first sample) depends on the inputs 2^d j - 10 (2^d - 1) ... 2^d j,
+// so it is exact once j >= 10 - 10 / 2^d: the first ceil(..) outputs of a segment are warm-up and are
+// not emitted.  Returned in input samples, rounded up to a multiple of 16 (the emit test of the
+// register stages is per lane = per 16 samples); always a multiple of 2^d.
+int warmup_samples(int d)
 {
-    // A segment that starts mid-frame starts from zero state.  Stage s's 16-sample carry is
-    // made of real samples again once 26 * 2^s input samples have gone by (10 * (2^s - 1) until
-    // its inputs are valid + 16 of them), so run that many whole chunks before emitting.
     if (d <= 0)
         return 0;
-    return (26 * (1 << (d - 1)) + kChunk - 1) / kChunk;
+    const int vd = (10 * ((1 << d) - 1) + (1 << d) - 1) >> d;        // ceil(10 (2^d - 1) / 2^d)
+    int w = vd << d;
+    while (w & 15)
+        w += 1 << d;
+    return w;
 }
 
 hipEvent_t get_event(sdrx_ctx *c)
@@ -591,24 +597,42 @@ int sdrx_finalize(sdrx_ctx *c)
         level_nseg[(size_t)lv] = std::max(1, (ncu * 32 + level_count[(size_t)lv] - 1) / level_count[(size_t)lv]);
     for (int i = 0; i < N; ++i) {
         const Node &n = c->nodes[(size_t)i];
-        const int nchunks = (n.d.samples_per_buffer + kChunk - 1) / kChunk;
-        const int W = warmup_chunks(n.d.decimate_count);
+        const int n_in = n.d.samples_per_buffer;
+        const int nchunks = (n_in + kChunk - 1) / kChunk;
+        const int warm = warmup_samples(n.d.decimate_count);
+        const int wch = (warm + kChunk - 1) / kChunk; // chunks a segment spends before its first exact output
         // few VFOs in the level (the 2-3 mains): segments as short as the warm-up allows;
-        // otherwise at least 4 chunks (and 4 W) of useful work per segment
+        // otherwise at least 4 chunks of useful work per segment
         const bool few = (long long)level_count[(size_t)n.level] * nchunks < (long long)ncu * 16;
-        const int min_seg = few ? std::max(1, W) : std::max(4, 4 * W);
+        const int min_seg = few ? std::max(1, wch) : std::max(4, 4 * wch);
         int nseg = c->opt_segments > 0 ? c->opt_segments : std::min(level_nseg[(size_t)n.level], std::max(1, nchunks / min_seg));
-        nseg = std::max(1, std::min(nseg, nchunks / std::max(1, W)));
-        for (int s = 0; s < nseg; ++s) {
+        nseg = std::max(1, std::min(nseg, nchunks / std::max(1, wch)));
+        // Segment s > 0 starts `warm` samples before its first emitted output and ends on a chunk
+        // boundary of ITS OWN walk (s_begin + a whole number of chunks), so the warm-up costs the
+        // first `warm / 16` lanes of its first chunk instead of a whole extra chunk; the boundaries
+        // between segments are therefore not multiples of 1024.
+        // ... unless the whole-chunk warm-up costs little anyway (long VFO-frames cut into few segments:
+        // < 4 % extra chunks): then segments stay tile aligned, which keeps the kernel's uniform
+        // addressing (measured: the per-lane form costs 2-5 % per chunk).
+        const bool shifted = (long long)(nseg - 1) * wch * 25 > nchunks;
+        const int lead = shifted ? warm : wch * kChunk; // samples a segment walks before its first emitted output
+        const long long target = ((long long)n_in + nseg - 1) / nseg; // samples a segment should emit
+        int first_out = 0;                                            // input position of the first output the next segment emits
+        while (first_out < n_in) {
             K1Work w;
             w.vfo = i;
-            w.c_first_out = (int)((long long)nchunks * s / nseg);
-            w.c_end = (int)((long long)nchunks * (s + 1) / nseg);
-            w.c_begin = s == 0 ? 0 : w.c_first_out - W;
-            if (w.c_begin < 0)
-                return fail(c, SDRX_EUNSUPPORTED, "vfo %d: %d segments do not leave room for %d warm-up chunks", i, nseg, W);
-            if (w.c_end > w.c_first_out)
-                works[(size_t)n.level].push_back(w);
+            w.s_first_out = first_out;
+            w.s_begin = first_out == 0 ? 0 : first_out - lead;
+            if (w.s_begin < 0)
+                return fail(c, SDRX_EUNSUPPORTED, "vfo %d: %d segments do not leave room for the %d-sample warm-up", i, nseg, warm);
+            long long k = ((long long)(first_out - w.s_begin) + target + kChunk / 2) / kChunk; // chunks of this segment's walk
+            k = std::max<long long>(k, lead / kChunk + 1);                                     // it must emit something
+            long long end = w.s_begin + k * kChunk;
+            if (end + lead + kChunk / 2 >= n_in) // what would be left is not worth a segment of its own
+                end = n_in;
+            w.s_end = (int)std::min<long long>(n_in, end);
+            works[(size_t)n.level].push_back(w);
+            first_out = w.s_end;
         }
     }
     // Order of the work items inside a launch (experiment switch SDRX_ORDER, default = VFO-major,
@@ -617,7 +641,7 @@ int sdrx_finalize(sdrx_ctx *c)
     if (const char *e = getenv("SDRX_ORDER")) {
         if (atoi(e) == 1) // segment-major: all first segments, then all second segments, ...
             for (auto &wl : works)
-                std::stable_sort(wl.begin(), wl.end(), [](const K1Work &a, const K1Work &b) { return a.c_first_out < b.c_first_out; });
+                std::stable_sort(wl.begin(), wl.end(), [](const K1Work &a, const K1Work &b) { return a.s_first_out < b.s_first_out; });
     }
     c->l1.clear();
     for (int lv = 0; lv < c->n_levels; ++lv) {

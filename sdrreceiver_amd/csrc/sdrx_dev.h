@@ -32,11 +32,13 @@ struct K1Vfo {
     int out_tiled;         // 1: children consume the output (tile layout); 0: natural order for the demod
 };
 
-// One wave's job: chunks [c_begin, c_end) of one VFO-frame; chunks before c_first_out only warm
-// the filter state up (mid-frame segment start) and emit nothing.
+// One wave's job: samples [s_begin, s_end) of one VFO-frame, walked in 1024-sample chunks (all three
+// are multiples of 16 and of 2^d; s_end - s_begin is a whole number of chunks except at the frame's
+// end).  A segment that starts inside the frame starts from zero filter state: its outputs are exact
+// from input position s_first_out = s_begin + warm-up on, and only those are emitted.
 struct K1Work {
     int vfo;
-    int c_begin, c_first_out, c_end;
+    int s_begin, s_first_out, s_end;
 };
 
 // One block's job in the block-per-tile kernels (late decimation, demod, compress).
