@@ -631,6 +631,20 @@ int sdrx_finalize(sdrx_ctx *c)
             if (end + lead + kChunk / 2 >= n_in) // what would be left is not worth a segment of its own
                 end = n_in;
             w.s_end = (int)std::min<long long>(n_in, end);
+            if (w.s_end == n_in && w.s_begin > 0) {
+                // The chunk that holds the frame's last sample saves the filter history for the next
+                // frame from the registers of its last TWO lanes and from the tail of the LDS stages:
+                // like a tile-aligned frame (checked above), a shifted walk must end in a chunk of
+                // at least 256 samples.  Start earlier if it does not -- more warm-up is always exact.
+                const int r = (n_in - w.s_begin) & (kChunk - 1);
+                if (r != 0 && r < 256) {
+                    const int unit = std::max(16, 1 << n.d.decimate_count);
+                    const int delta = (256 - r + unit - 1) / unit * unit;
+                    w.s_begin = std::max(0, w.s_begin - delta); // (0 = walk from the frame's start with the real history)
+                    if (w.s_begin == 0)
+                        w.s_first_out = first_out;
+                }
+            }
             works[(size_t)n.level].push_back(w);
             first_out = w.s_end;
         }

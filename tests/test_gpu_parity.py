@@ -576,6 +576,34 @@ def test_contexts_do_not_leak_device_memory(Receiver):
     assert free0 - free1 < 8 << 20, (free0, free1)  # a context of this profile holds ~30 MB: 30 leaked ones would show
 
 
+def _short_chunk_cases():
+    fixed = [(5056, 2), (5760, 5), (5760, 7), (5072, 3), (8704, 4)]
+    rng = np.random.default_rng(77)
+    sweep = [(int(64 * rng.integers(70, 260)), int(rng.integers(2, 9))) for _ in range(35)]
+    return fixed + [(f, sg) for f, sg in sweep if f % 1024 == 0 or f % 1024 >= 256]
+
+
+@pytest.mark.parametrize("frame,segments", _short_chunk_cases())
+def test_segments_whose_walk_ends_in_a_short_chunk(Receiver, frame, segments):
+    """A segment that starts inside the frame walks from `first emitted sample - warm-up`, so its
+    chunks are not aligned with the frame's: the frame's last samples may end up in a chunk of
+    16 ... 240 samples.  The filter history saved there for the next frame (two lanes for stage 1)
+    must still be complete: depths 1-6 on frames picked so that exactly this happens, 5 frames."""
+    t = tp.Topology(fs=frame * 4, frame=frame, name="shortlast")
+    for d in range(1, 7):
+        if frame % (16 << max(0, d - 4)) or frame % (1 << d):
+            continue
+        t.vfos.append(tp.VfoDesc(topic=f"S{d}", parent=-1, fs=frame * 4, decimate_count=d, mixer_freq=float(900 + 211 * d),
+                                 gain=tp._g(0.05), cstyle=1, samples_per_buffer=frame))
+    rx = Receiver.from_topology(t, exact=True, segments=segments)
+    nodes, roots = ob.build_tree("port", t)
+    for f, iq in _frames(t, 4, seed=23, tones=[(2500.0, 25.0)]):
+        rx.process(iq)
+        ob.process_roots(roots, iq)
+        _check_exact(rx, nodes, t, ("shortlast", frame, segments, f))
+    rx.close()
+
+
 def test_three_level_tree(Receiver):
     """vfo::process recurses (vfo.cpp:253-264); the reference only builds two levels, the library
     takes any depth: raw -> d=2 -> d=1 -> {d=2 USB leaf with low-pass, d=0 USB leaf, d=3 IQ leaf}."""
