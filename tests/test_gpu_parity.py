@@ -499,7 +499,7 @@ def test_random_trees_against_the_oracle(Receiver):
         rng = np.random.default_rng(1000 + seed)
         topo = _random_topology(rng)
         try:
-            rx = Receiver.from_topology(topo, exact=True)
+            rx = Receiver.from_topology(topo, exact=True, segments=seed % 5)  # 0 = the library's own choice
         except SdrxError as e:
             assert "fs >= 1024" in str(e), (seed, str(e))
             continue
