@@ -520,11 +520,11 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
 #else
     const int first_out = D.n_in == 12345 ? W.s_first_out : 0x7fffffff; // ablation: nothing is ever emitted
 #endif
-    const bool aligned = (W.s_begin & (kChunk - 1)) == 0; // wave-uniform
+    const int lane16 = (W.s_begin >> 4) + lane; // this lane's run in the item's first chunk, in units of 16 samples
+    const float4 *src_item = in + tile_unit(lane16 >> 6, 0, lane16 & 63);
     for (int base = W.s_begin; base < W.s_end; base += kChunk) {
         const int valid = min(kChunk, D.n_in - base);
         const int p16 = (base >> 4) + lane;               // this lane's run, in units of 16 samples
-        const int p16c = min(p16, (D.n_in >> 4) - 1);     // ... clamped into the frame, for addressing the input
         const bool emit = base + kChunk > first_out;      // the chunk reaches into the emitted range
         const bool emit_l = (p16 << 4) >= first_out;      // ... and this lane's run lies inside it
         const bool save = base + valid == D.n_in;         // the chunk that holds the frame's last sample
@@ -563,11 +563,11 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
                 }
             }
         } else {
-            // An item whose walk is tile aligned addresses its chunk uniformly (scalar tile base + lane);
-            // a shifted walk straddles two tiles: per-lane tile and position.  Lanes past the frame's
-            // end re-read the last real run: their own tile may not exist, and nothing they compute
-            // is stored or reaches a lane that is.
-            const float4 *src = aligned ? in + tile_unit(base >> 10, 0, lane) : in + tile_unit(p16c >> 6, 0, p16c & 63);
+            // The lane's position inside its tile is the same in every chunk of the item (the walk
+            // advances by exactly one tile per chunk): src_item is computed once, a chunk adds 512
+            // units.  A shifted walk straddles two tiles; its idle lanes in the frame's last chunk may
+            // read the (zero) tile behind the last one, which every tile-layout buffer has.
+            const float4 *src = src_item + (size_t)((base - W.s_begin) >> 10) * 512;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #ifndef SDRX_ABL_LOAD

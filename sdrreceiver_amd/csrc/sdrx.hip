@@ -545,7 +545,7 @@ int sdrx_finalize(sdrx_ctx *c)
             }
         }
         for (int p = 0; p < 2; ++p) // a stream that feeds children is kept in whole 1024-sample tiles
-            n.off_stream[p] = plan.take(sizeof(float2) * (n.leaf ? (size_t)(n.Hx + n.n_f) : align_up((size_t)n.n_f, kChunk)));
+            n.off_stream[p] = plan.take(sizeof(float2) * (n.leaf ? (size_t)(n.Hx + n.n_f) : align_up((size_t)n.n_f, kChunk) + kChunk)); // (+1 tile: a shifted walk's idle lanes read past the last one)
         if (late)
             for (int p = 0; p < 2; ++p)
                 n.off_z[p] = plan.take(sizeof(float2) * (size_t)(n.H + n.n_out));
@@ -613,7 +613,8 @@ int sdrx_finalize(sdrx_ctx *c)
         // between segments are therefore not multiples of 1024.
         // ... unless the whole-chunk warm-up costs little anyway (long VFO-frames cut into few segments:
         // < 4 % extra chunks): then segments stay tile aligned, which keeps the kernel's uniform
-        // addressing (measured: the per-lane form costs 2-5 % per chunk).
+        // walk on the tiles (measured on the memory-bound flat workload: a walk that straddles two
+        // tiles per chunk costs 5 %).
         const bool shifted = (long long)(nseg - 1) * wch * 25 > nchunks;
         const int lead = shifted ? warm : wch * kChunk; // samples a segment walks before its first emitted output
         const long long target = ((long long)n_in + nseg - 1) / nseg; // samples a segment should emit
@@ -774,7 +775,7 @@ int sdrx_finalize(sdrx_ctx *c)
     memset(c->h_pay, 0, c->pay_bytes);
 
     {
-        const size_t raw_tiles = align_up((size_t)c->root_frame, kChunk);
+        const size_t raw_tiles = align_up((size_t)c->root_frame, kChunk) + kChunk; // (+1 tile, as for the parents' streams)
         HIPCHK(c, hipMalloc(&c->d_raw_tiled, raw_tiles * sizeof(float2)));
         HIPCHK(c, hipMemsetAsync(c->d_raw_tiled, 0, raw_tiles * sizeof(float2), c->stream));
         c->root_direct = level_count[0] <= 4 && !getenv("SDRX_NO_ROOT_DIRECT"); // the reference allows 3 mains (mainwindow.h:82)
