@@ -642,8 +642,6 @@ int sdrx_finalize(sdrx_ctx *c)
                     const int unit = std::max(16, 1 << n.d.decimate_count);
                     const int delta = (256 - r + unit - 1) / unit * unit;
                     w.s_begin = std::max(0, w.s_begin - delta); // (0 = walk from the frame's start with the real history)
-                    if (w.s_begin == 0)
-                        w.s_first_out = first_out;
                 }
             }
             works[(size_t)n.level].push_back(w);
