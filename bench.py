@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the per-VFO IQ chain on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3|flat|config2|config4|config5|10k|64k|256k]
-                    [--fast] [--no-cpu] [--configs1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R]
+                    [--workload config3|flat|config2|config4|config5|10k|64k|256k]
+                    [--fast] [--no-cpu] [--no-abi] [--configs1] [--batch B]
 
 A "step" is one pass of the hot path over one raw IQ frame (250 ms of signal: 384 000 cf32 at
-1.536 MS/s), already resident in HBM, through every VFO of the workload.  Default workload =
-BASELINE.json config 3: the two sdr_25E main VFOs with 512 sub VFOs each (1 024 sub VFOs; main0
-subs 384 k -> 12 k, main1 subs 192 k -> 48 k, every 2nd with the 47-tap 10 kHz low-pass).
+1.536 MS/s), already resident in HBM, through every VFO of the workload.
 
-Multi-GPU (one process per GPU under torch.distributed.run): the sub VFOs shard across ranks
-with no data-path collective except the one the path really has -- the raw frame is broadcast
-from rank 0 over RCCL every step.  Weak scaling: every rank runs the full single-GPU workload
-(N x 1 024 sub VFOs in total).
+Workload.  N = 1 (the BENCH line): BASELINE.json config 3 -- the two sdr_25E main VFOs with 512
+sub VFOs each (1 024 sub VFOs; main0 subs 384 k -> 12 k, main1 subs 192 k -> 48 k, every 2nd with
+the 47-tap 10 kHz low-pass).  N > 1 (the SCALE lines): BASELINE.json config 5 -- the same tree
+with 65 536 sub VFOs IN TOTAL, sharded over the N GPUs (strong scaling: 65 536 / N per GPU,
+mains replicated), raw frames broadcast from rank 0 over RCCL; the weak-scaled config-3 reading
+(1 024 sub VFOs per GPU) is measured in the same run and reported as the side object
+`weak_config3`.  `--workload` overrides either default.
+
+Timing.  W untimed warm-up steps (plus enough extra to reach ~50 ms of GPU time: the clock ramps),
+then the timed region -- EXACTLY K steps between barrier + torch.cuda.synchronize() on both sides,
+max over ranks -- is repeated R times (default 15); `ms_per_step` and `value` are the MEDIAN
+repetition, min / max are in `ms_per_step_min/max`.
 
 Prints ONE JSON line (rank 0).  `value` = IQ MSamples/s ingested, summed over every VFO chain of
 every rank (the unit that scales with the number of VFOs); `raw_iq_msps` and `vfos_at_realtime`
@@ -23,6 +30,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD = 256 * 4       # 256 CUs x 4 SIMDs
 
 
 def make_topology(name, world):
@@ -45,7 +54,8 @@ def make_topology(name, world):
     if name == "10k":
         return tp.config3(10240 * world), "north-star target: 10 240 sub VFOs per GPU under the 2 sdr_25E mains"
     if name == "config5":
-        return tp.config5(65536), "BASELINE config 5: 65 536 sub VFOs in total, sharded over the GPUs (strong scaling), raw frame broadcast"
+        return tp.config5(65536), (f"BASELINE config 5: 65 536 sub VFOs in total under the 2 sdr_25E mains, sharded over {world} GPU(s) "
+                                   "(strong scaling), raw frames broadcast from rank 0")
     if name == "256k":
         return tp.config3(262144 * world), "memory-scale check: 262 144 sub VFOs per GPU under the 2 sdr_25E mains (~70 GB of HBM)"
     if name == "64k":
@@ -58,7 +68,6 @@ def cpu_baseline(workload):
     cores.  Prefers the real reference build (oracle/_ref, kind "reference", one thread -- how
     the reference actually runs); falls back to the plain-C restatement (kind
     "port").  The all-cores OpenMP figure of the port is reported next to it."""
-    import numpy as np
     from oracle import binding as ob
     from sdrreceiver_amd import synth, topology as tp
     if workload == "flat":
@@ -107,15 +116,82 @@ def cpu_baseline(workload):
     return out
 
 
+def pmc_for(workload, exact):
+    """profiles/current_pmc.json (tools/profile.sh + tools/pmc_summary.py): per-launch counter means of
+    the committed PMC passes, if they were taken on this workload and arithmetic."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "current_pmc.json")))
+    except (OSError, ValueError):
+        return None
+    if pm.get("workload") != workload or pm.get("exact") != exact:
+        return None
+    return pm
+
+
+def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix_chunks):
+    """SURVEY.md 8d's contract figure (algorithmic bytes / launch duration vs 8 TB/s) plus what the
+    counters say actually bounds the launch: real HBM traffic, L2 hit rate, VALU issue."""
+    dom_bytes = d["alg_bytes"] / d["launches"]
+    dom_avg_s = d["ms"] / d["launches"] * 1e-3
+    achieved = dom_bytes / dom_avg_s / 1e9
+    r = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+         "bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 5),
+         "frame_kernel_ms": round(frame_kernel_ms, 5),
+         "frame_frac": round(alg_bytes / world / (frame_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    k = pm["kernels"].get(dom) if pm else None
+    if not k:
+        r["limited_by"] = "unknown here: no committed PMC passes for this workload (tools/profile.sh)"
+        return r
+    cn = k.get("counters", {})
+    r["traffic_source"] = pm.get("source")
+    r["pmc_git_sha"] = pm.get("git_sha")
+    if "hbm_bytes_per_launch" in k:
+        r["traffic"] = int(k["hbm_bytes_per_launch"])
+        r["hbm_true_GBps"] = round(r["traffic"] / dom_avg_s / 1e9, 1)
+        r["hbm_true_frac"] = round(r["traffic"] / dom_avg_s / 1e9 / HBM_PEAK_GBS, 4)
+        r["traffic_over_algorithmic"] = round(r["traffic"] / dom_bytes, 3)
+    if "l2_hit_rate" in k:
+        r["l2_hit_rate"] = k["l2_hit_rate"]
+    if "SQ_ACTIVE_INST_VALU" in cn and "GRBM_GUI_ACTIVE" in cn:
+        # SQ_ACTIVE_INST_* count quad-cycles summed over all SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        launch_cycles = cn["GRBM_GUI_ACTIVE"] / 8.0
+        busy = 4.0 * cn["SQ_ACTIVE_INST_VALU"] / N_SIMD
+        valu = {"wave_insts_per_launch": int(cn.get("SQ_INSTS_VALU", 0)),
+                "busy_cycles_per_simd": int(busy), "launch_cycles": int(launch_cycles),
+                "busy_frac": round(busy / launch_cycles, 3),
+                "cycles_per_inst": round(4.0 * cn["SQ_ACTIVE_INST_VALU"] / max(1.0, cn.get("SQ_INSTS_VALU", 1.0)), 2),
+                "clock_GHz_during_pmc_pass": round(launch_cycles / (k.get("avg_us", dom_avg_s * 1e6) * 1e3), 3) if k.get("avg_us") else None}
+        if mix_chunks and dom.startswith("k_mix_decimate"):
+            valu["insts_per_1024_sample_chunk"] = round(cn.get("SQ_INSTS_VALU", 0) / mix_chunks, 1)
+        if "inst_mix" in pm:
+            valu["inst_mix_per_chunk"] = pm["inst_mix"]
+        if "SQ_WAVE_CYCLES" in cn:
+            wc = cn["SQ_WAVE_CYCLES"]
+            valu["wave_cycles_split"] = {kk: round(cn[kk] / wc, 3) for kk in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if kk in cn}
+        if "SQ_ACTIVE_INST_LDS" in cn:
+            valu["lds_busy_frac"] = round(4.0 * cn["SQ_ACTIVE_INST_LDS"] / N_SIMD / launch_cycles, 3)
+        r["valu"] = valu
+        hb = r.get("hbm_true_frac", 0.0)
+        r["limited_by"] = (f"VALU issue ({valu['busy_frac']:.0%} of the launch's cycles busy) -- not HBM: real traffic is "
+                           f"{hb:.0%} of the 8 TB/s peak, siblings share the parent's stream through L2"
+                           if valu["busy_frac"] > hb else f"HBM ({hb:.0%} of peak in real traffic)")
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="config3")
+    ap.add_argument("--reps", type=int, default=15, help="repetitions of the timed K-step region (median reported)")
+    ap.add_argument("--workload", default=None)
     ap.add_argument("--fast", action="store_true", help="FMA arithmetic (within 1e-6 of the reference) instead of bit-exact")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-abi", action="store_true", help="skip the through-the-ABI (host buffers, PCIe both ways) leg")
+    ap.add_argument("--no-pipeline", action="store_true", help="leaf tail on the same stream as the levels (A/B switch)")
     ap.add_argument("--segments", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0, help="frames per broadcast at N > 1 (default 4)")
     ap.add_argument("--configs1", action="store_true",
                     help="also time BASELINE configs[1] (32 sub VFOs) and report it as a side reading (off by default: the "
                          "profiled default command must launch the kernels of ONE workload only)")
@@ -132,6 +208,7 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libsdrx has no CPU fallback)")
+    workload = args.workload or ("config3" if world == 1 else "config5")
     # SDRX_BENCH_SHARE_GPU=1 (validation on a 1-GPU box only): all ranks on device 0, gloo instead of
     # RCCL (which refuses two ranks on one device).  The numbers of such a run mean nothing.
     share = os.environ.get("SDRX_BENCH_SHARE_GPU") == "1"
@@ -144,42 +221,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         D.init_process_group("gloo" if share else "nccl", device=torch.device("cuda", local))
-
-    full, descr = make_topology(args.workload, world)
-    topo = tp.shard(full, rank, world)
-    rx = Receiver.from_topology(topo, device=local, exact=not args.fast, segments=args.segments)
+    dev = torch.device("cuda", local)
     stream = torch.cuda.Stream()  # a real (non-null) stream shared by torch, RCCL ordering and our kernels
     torch.cuda.set_stream(stream)
-    rx.set_stream(stream.cuda_stream)
-    st = rx.stats()
-
-    # the raw frame lives in HBM; rank 0 owns the source, the others receive it by broadcast
-    frame_np = synth.lcg_frame(topo.frame, synth.Lcg(1))
-    src = torch.from_numpy(frame_np).cuda() if rank == 0 else None
-    bcast = D.FrameBroadcast(topo.frame, torch.device("cuda", local), src_rank=0)  # RCCL over xGMI: the only exchange
-
-    # The broadcast of frame k+1 (RCCL, its own stream) overlaps the processing of frame k; at N = 1
-    # submit/result hand the resident frame straight through.
-    overlap = True
-    try:
-        bcast.submit(src)
-        bcast.result()
-        bcast.consumed()
-        bcast.submit(src)
-    except Exception as e:  # fall back to the serial broadcast rather than lose the run
-        overlap = False
-        if rank == 0:
-            print(f"bench: overlapped broadcast unavailable ({type(e).__name__}: {e}); broadcasting in line", file=sys.stderr)
-
-    def step(k):
-        if not overlap:
-            b = bcast(src)
-            rx.process_device(b.data_ptr(), topo.frame)
-            return
-        b = bcast.result()
-        rx.process_device(b.data_ptr(), topo.frame)
-        bcast.consumed()
-        bcast.submit(src)
+    batch = args.batch or (4 if world > 1 else 1)
 
     def barrier():
         torch.cuda.synchronize()
@@ -187,104 +232,223 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    def allmax(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        tot = torch.tensor([float(st["vfo_samples_per_frame"]), float(st["algorithmic_bytes_per_frame"]),
-                            float(st["n_leaves"])], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        vfo_samples, alg_bytes, n_leaves = (float(x) for x in tot.tolist())
-    else:
-        vfo_samples, alg_bytes, n_leaves = float(st["vfo_samples_per_frame"]), float(st["algorithmic_bytes_per_frame"]), float(st["n_leaves"])
+        return float(t.item())
 
-    # second, separate pass with HIP events around every kernel launch (on the launch stream):
+    def allsum(vals):
+        if world == 1:
+            return [float(v) for v in vals]
+        t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(x) for x in t.tolist()]
+
+    class Job:
+        """One workload on this rank's shard: the Receiver, the raw-frame source and the broadcast."""
+
+        def __init__(self, name):
+            self.full, self.descr = make_topology(name, world)
+            self.topo = tp.shard(self.full, rank, world)
+            self.frame = self.full.frame
+            self.rx = Receiver.from_topology(self.topo, device=local, exact=not args.fast, segments=args.segments,
+                                             pipeline=not args.no_pipeline) if self.topo.vfos else None
+            if self.rx:
+                self.rx.set_stream(stream.cuda_stream)
+            self.st = self.rx.stats() if self.rx else {"vfo_samples_per_frame": 0, "algorithmic_bytes_per_frame": 0, "n_leaves": 0,
+                                                        "mix_chunks_per_frame": 0}
+            # the raw frames live in HBM; rank 0 owns the source (`batch` different frames), the others
+            # receive them by broadcast -- the ONLY exchange of the path (RCCL over xGMI)
+            lcg = synth.Lcg(1)
+            self.frames_np = [synth.lcg_frame(self.frame, lcg) for _ in range(batch)]
+            self.src = torch.from_numpy(np.concatenate(self.frames_np)).to(dev) if rank == 0 else None
+            self.bcast = D.FrameBroadcast(self.frame, dev, src_rank=0, frames_per_batch=batch)
+            self.cur = None
+            self.overlap = True
+            try:  # the broadcast of batch k+1 (RCCL, its own stream) overlaps the processing of batch k
+                self.bcast.submit(self.src)
+            except Exception as e:  # fall back to the serial broadcast rather than lose the run
+                self.overlap = False
+                if rank == 0:
+                    print(f"bench: overlapped broadcast unavailable ({type(e).__name__}: {e}); broadcasting in line", file=sys.stderr)
+
+        def step(self, k, fetch=False):
+            j = k % batch
+            if j == 0:
+                self.cur = self.bcast.result() if self.overlap else self.bcast(self.src)
+            if self.rx:
+                self.rx.process_device(self.cur.data_ptr() + j * self.frame * 8, self.frame)
+                if fetch:
+                    self.rx.fetch()
+            if j == batch - 1 and self.overlap:
+                self.bcast.submit(self.src)  # one event: batch consumed, next one may travel
+
+        def timed(self, steps, fetch=False):
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                self.step(k, fetch)
+            barrier()
+            return allmax(time.perf_counter() - t0)
+
+        def measure(self, steps, warmup, reps):
+            for k in range(warmup):
+                self.step(k)
+            self.realign(warmup)
+            dt = self.timed(steps)          # also tells how many more warm-up steps make ~50 ms of GPU time
+            self.realign(steps)
+            extra = int(min(2000, max(0, 0.05 / max(dt / steps, 1e-7) - steps - warmup)))
+            for k in range(extra):
+                self.step(k)
+            self.realign(extra)
+            out = []
+            for _ in range(reps):
+                out.append(self.timed(steps))
+                self.realign(steps)
+            return out
+
+        def realign(self, steps_done):
+            """Finish a partly used batch so that the next region starts at a batch boundary."""
+            k = steps_done % batch
+            while k % batch:
+                self.step(k)
+                k += 1
+
+        def close(self):
+            if self.overlap:
+                self.bcast.result()  # drain the broadcast that is still in flight before the process group goes away
+            barrier()
+            if self.rx:
+                self.rx.close()
+
+    job = Job(workload)
+    topo, rx, st, full, descr = job.topo, job.rx, job.st, job.full, job.descr
+    reps = job.measure(args.steps, args.warmup, max(1, args.reps))
+    dt = statistics.median(reps)
+    vfo_samples, alg_bytes, n_leaves = allsum([st["vfo_samples_per_frame"], st["algorithmic_bytes_per_frame"], st["n_leaves"]])
+
+    # second, separate pass with HIP events around every kernel launch (on the launch's stream):
     # the dominant kernel's average duration for the roofline object
-    rx.enable_kernel_timing(True)
-    for k in range(min(args.steps, 20)):
-        step(k)
-    barrier()
-    kt = rx.kernel_times()
-    rx.enable_kernel_timing(False)
-    # third: with the payload D2H copy + publish callbacks in the loop (never `value`)
-    barrier()
-    t1 = time.perf_counter()
-    for k in range(min(args.steps, 10)):
-        step(k)
-        rx.fetch()
-    barrier()
-    dt_d2h = (time.perf_counter() - t1) / min(args.steps, 10)
-    # fourth: the same without the (Python, ctypes) callbacks -- what a C / C++ host sees: kernels + payload D2H
-    rx.set_publish(False)
-    barrier()
-    t1 = time.perf_counter()
-    for k in range(min(args.steps, 10)):
-        step(k)
-        rx.fetch()
-    barrier()
-    dt_d2h_nocb = (time.perf_counter() - t1) / min(args.steps, 10)
-    rx.set_publish(True)
+    kt, kt_steps = {}, min(args.steps, 20)
+    if rx:
+        rx.enable_kernel_timing(True)
+        for k in range(kt_steps):
+            job.step(k)
+        job.realign(kt_steps)
+        barrier()
+        kt = rx.kernel_times()
+        rx.enable_kernel_timing(False)
+    else:
+        barrier()
+
+    # third (N = 1): through the C ABI from HOST buffers -- what a Qt / C++ host sees, PCIe both ways.
+    abi = None
+    if world == 1 and not args.no_abi and rx:
+        n_abi = max(8, min(args.steps, 24))
+        pay_mb = sum(topo.vfos[i].n_out * 2 if topo.vfos[i].demod_usb else topo.vfos[i].n_stage_out
+                     for i in topo.leaves_in_publish_order()) / 1e6
+
+        def host_loop(kind):
+            f32 = job.frames_np[0]
+            u8 = (f32 + 127).astype(np.uint8)
+            pinned = torch.from_numpy(f32.copy()).pin_memory().numpy()
+            best = []
+            for _ in range(3):
+                barrier()
+                t0 = time.perf_counter()
+                if kind == "sync_pageable":      # sdrx_process per frame: submit + wait, nothing overlaps
+                    for _k in range(n_abi):
+                        rx.process(f32)
+                elif kind == "sync_pinned":
+                    for _k in range(n_abi):
+                        rx.process(pinned)
+                else:                            # the pipelined interface: submit(f+1); wait() -> f
+                    src = {"pipelined_pageable": f32, "pipelined_pinned": pinned, "pipelined_u8": u8}[kind]
+                    sub = rx.submit_u8 if kind == "pipelined_u8" else rx.submit
+                    sub(src)
+                    for _k in range(1, n_abi):
+                        sub(src)
+                        rx.wait()
+                    rx.wait()
+                barrier()
+                best.append((time.perf_counter() - t0) / n_abi)
+            return round(statistics.median(best) * 1e3, 4)
+
+        rx.set_publish(False)  # a ctypes callback costs microseconds per leaf: a C host pays nanoseconds
+        abi = {"frames": n_abi, "payload_MB_per_frame": round(pay_mb, 2), "input_MB_per_frame": round(topo.frame * 8 / 1e6, 2),
+               "note": "host float/byte frame in, int16 payloads in host memory out, publish callbacks off; median of 3"}
+        for kind in ("sync_pageable", "sync_pinned", "pipelined_pageable", "pipelined_pinned", "pipelined_u8"):
+            abi[kind + "_ms"] = host_loop(kind)
+        rx.set_publish(True)
+        t1 = time.perf_counter()
+        for _k in range(4):
+            rx.process(job.frames_np[0])
+        abi["sync_with_python_callbacks_ms"] = round((time.perf_counter() - t1) / 4 * 1e3, 4)
+
+    weak = None
+    if world > 1 and workload == "config5":
+        # side reading: the weak-scaled config-3 workload (1 024 sub VFOs per GPU), the N = 1 BENCH workload
+        job.close()
+        job = None
+        try:
+            wj = Job("config3")
+            wreps = wj.measure(args.steps, args.warmup, max(1, min(args.reps, 7)))
+            wdt = statistics.median(wreps)
+            ws, wa, wl = allsum([wj.st["vfo_samples_per_frame"], wj.st["algorithmic_bytes_per_frame"], wj.st["n_leaves"]])
+            weak = {"workload": wj.descr, "scaling": "weak", "ms_per_step": round(wdt / args.steps * 1e3, 4),
+                    "value": round(args.steps * ws / wdt / 1e6, 2), "unit": "MSamples/s",
+                    "algorithmic_GBps_whole_job": round(args.steps * wa / wdt / 1e9, 1), "sub_vfos_total": int(wl)}
+            wj.close()
+        except Exception as e:
+            weak = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        frame_seconds = topo.frame / topo.fs
+        frame_seconds = full.frame / full.fs
         value = args.steps * vfo_samples / dt / 1e6
         kernels = {}
         dom, dom_ms = None, -1.0
         frame_kernel_ms = 0.0
         for name, r in kt.items():
             avg = r["ms"] / r["launches"]
-            per_frame = r["ms"] / min(args.steps, 20)
+            per_frame = r["ms"] / kt_steps
             frame_kernel_ms += per_frame
-            kernels[name] = {"avg_ms": round(avg, 5), "launches_per_frame": r["launches"] // min(args.steps, 20),
+            kernels[name] = {"avg_ms": round(avg, 5), "launches_per_frame": r["launches"] // kt_steps,
                              "kernel_bytes_per_launch": r["alg_bytes"] // r["launches"],
                              "GBps": round(r["alg_bytes"] / r["launches"] / (avg * 1e-3) / 1e9, 1)}
             if per_frame > dom_ms:
                 dom, dom_ms = name, per_frame
-        # Roofline of the dominant kernel.  Algorithmic bytes (8*n_in + W_out per
-        # VFO per frame) for the VFOs that kernel processes in one launch / its average duration.
-        d = kt[dom]
-        dom_bytes = d["alg_bytes"] / d["launches"]
-        dom_avg_s = d["ms"] / d["launches"] * 1e-3
-        achieved = dom_bytes / dom_avg_s / 1e9
-        traffic, traffic_src = None, None
-        try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/profile.sh)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "current_pmc.json")))
-            if pm.get("workload") == args.workload and pm.get("exact") == (not args.fast):
-                k = pm["kernels"].get(dom)
-                if k:
-                    traffic, traffic_src = int(k["hbm_bytes_per_launch"]), pm.get("source")
-        except (OSError, ValueError, KeyError):
-            pass
         out = {
             "metric": "IQ MSamples/s ingested, summed over VFO chains (1.536 MS/s -> 48/12 kHz USB chain)",
             "value": round(value, 2), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if args.workload == "config5" else "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong" if workload == "config5" else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": descr, "name": full.name, "vfos_total": int(len(full.vfos)), "sub_vfos_per_gpu": int(st["n_leaves"]),
-                       "frame_cf32": topo.frame, "fs": topo.fs, "arithmetic": "fast-fma" if args.fast else "exact (bit-identical to -O2 reference)",
-                       "parallelism": f"vfo-shard x{world}, raw frame RCCL broadcast" if world > 1 else "single GPU"},
-            "raw_iq_msps": round(args.steps * topo.frame / dt / 1e6, 2),
+                       "frame_cf32": full.frame, "fs": full.fs, "arithmetic": "fast-fma" if args.fast else "exact (bit-identical to -O2 reference)",
+                       "parallelism": (f"vfo-shard x{world}, raw frames RCCL broadcast ({batch} per collective)" if world > 1 else "single GPU"),
+                       "frame_pipeline": "off" if args.no_pipeline else "leaf tail of frame f beside the levels of frame f+1 (2 HIP streams)"},
+            "repetitions": len(reps), "ms_per_step_min": round(min(reps) / args.steps * 1e3, 4),
+            "ms_per_step_max": round(max(reps) / args.steps * 1e3, 4),
+            "timed_region_ms_total": round(sum(reps) * 1e3, 1),
+            "raw_iq_msps": round(args.steps * full.frame / dt / 1e6, 2),
             "vfos_at_realtime": int(n_leaves * frame_seconds / (dt / args.steps)),
             "realtime_factor": round(frame_seconds / (dt / args.steps), 1),
             "algorithmic_GBps_whole_frame": round(args.steps * alg_bytes / dt / 1e9, 1),
-            "ms_per_step_with_payload_d2h_and_callbacks": round(dt_d2h * 1e3, 4),
-            "ms_per_step_with_payload_d2h": round(dt_d2h_nocb * 1e3, 4),
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 5),
-                         "frame_kernel_ms": round(frame_kernel_ms, 5),
-                         "frame_frac": round(alg_bytes / world / (frame_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "kernels": kernels,
+            "frame_frac_of_hbm_roofline": round(args.steps * alg_bytes / world / dt / 1e9 / HBM_PEAK_GBS, 4),
         }
+        if dom:
+            pm = pmc_for(workload, not args.fast)
+            out["roofline"] = roofline_object(dom, kt[dom], kt_steps, frame_kernel_ms, alg_bytes, world, pm, st["mix_chunks_per_frame"])
+        out["kernels"] = kernels
+        if abi:
+            out["through_abi"] = abi
+            out["ms_per_step_through_abi"] = abi["pipelined_pageable_ms"]
+            out["ms_per_step_with_payload_d2h"] = abi["sync_pageable_ms"]
+        if weak:
+            out["weak_config3"] = weak
         if world == 1 and args.configs1:
             # BASELINE.json configs[1] (32 sub VFOs), the same way, as a side reading: a latency-bound
             # plumbing case on this hardware (three ~10 us launches per frame)
@@ -294,11 +458,11 @@ def main():
                 rx2.set_stream(stream.cuda_stream)
                 st2 = rx2.stats()
                 for _ in range(args.warmup):
-                    rx2.process_device(src.data_ptr(), t2.frame)
+                    rx2.process_device(job.src.data_ptr(), t2.frame)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(args.steps):
-                    rx2.process_device(src.data_ptr(), t2.frame)
+                    rx2.process_device(job.src.data_ptr(), t2.frame)
                 torch.cuda.synchronize()
                 d2 = (time.perf_counter() - t0) / args.steps
                 rx2.close()
@@ -309,14 +473,12 @@ def main():
                 out["configs1_32_sub_vfos"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.workload)
+                out["cpu_baseline"] = cpu_baseline(workload)
             except Exception as e:  # the bench line must still come out
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
-    if overlap:
-        bcast.result()  # drain the broadcast that is still in flight before the process group goes away
-    barrier()
-    rx.close()
+    if job:
+        job.close()
     if world > 1:
         dist.destroy_process_group()
 

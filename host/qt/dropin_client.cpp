@@ -111,18 +111,11 @@ int dropin_run(const sdrx_vfo_desc *descs, int n, const char *addr, int frames, 
     std::vector<unsigned char> all;
     std::vector<cpx_typef> samples((size_t)root_frame);
     std::vector<unsigned char> part(1 << 20);
-    uint32_t x = 1; // BASELINE.md's LCG: x <- x*1664525 + 1013904223, component ((x >> 24) % 17) - 8
-    for (frame_no = 0; frame_no < frames; ++frame_no) {
-        for (auto &s : samples) {
-            x = x * 1664525u + 1013904223u;
-            const float re = (float)((int)((x >> 24) % 17u) - 8);
-            x = x * 1664525u + 1013904223u;
-            const float im = (float)((int)((x >> 24) % 17u) - 8);
-            s = cpx_typef(re, im);
-        }
-        for (vfo *m : mains) // sdrj.cpp:288-294
-            m->process(samples);
-        // drain: everything published for this frame (first recv waits up to the timeout)
+    // what the subscriber has received so far, in order; gives up after `first_ms` of silence (20 ms
+    // once a message of the burst has arrived: the rest of the frame's messages are already queued)
+    auto drain = [&](int first_ms) {
+        int timeout = first_ms;
+        zmq_setsockopt(sub, ZMQ_RCVTIMEO, &timeout, sizeof timeout);
         for (;;) {
             int r = zmq_recv(sub, part.data(), part.size(), 0);
             if (r < 0)
@@ -145,12 +138,24 @@ int dropin_run(const sdrx_vfo_desc *descs, int n, const char *addr, int frames, 
                 put32(all, (uint32_t)p.size());
                 all.insert(all.end(), p.begin(), p.end());
             }
-            timeout = 20; // the rest of the frame's messages are already queued
+            timeout = 20;
             zmq_setsockopt(sub, ZMQ_RCVTIMEO, &timeout, sizeof timeout);
         }
-        timeout = 300;
-        zmq_setsockopt(sub, ZMQ_RCVTIMEO, &timeout, sizeof timeout);
+    };
+    uint32_t x = 1; // BASELINE.md's LCG: x <- x*1664525 + 1013904223, component ((x >> 24) % 17) - 8
+    for (frame_no = 0; frame_no < frames; ++frame_no) {
+        for (auto &s : samples) {
+            x = x * 1664525u + 1013904223u;
+            const float re = (float)((int)((x >> 24) % 17u) - 8);
+            x = x * 1664525u + 1013904223u;
+            const float im = (float)((int)((x >> 24) % 17u) - 8);
+            s = cpx_typef(re, im);
+        }
+        for (vfo *m : mains) // sdrj.cpp:288-294
+            m->process(samples);
+        drain(300); // everything published for this frame (the first recv waits up to the timeout)
     }
+    drain(1500); // messages still on their way when the last frame's drain gave up (a loaded host)
     zmq_close(sub);
     zmq_ctx_term(zctx);
     for (vfo *m : mains)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SDRX_ABI_VERSION 1
+#define SDRX_ABI_VERSION 2
 
 enum {
     SDRX_OK = 0,
@@ -63,7 +63,9 @@ typedef struct sdrx_vfo_desc {
  * vfo::transmitData (vfo.cpp:426-453, zmqpublisher.h:16).  Invoked once per publishing leaf per
  * frame, in the reference's order: main VFOs in list order, their sub VFOs in list order
  * (sdrj.cpp:288-294, vfo.cpp:257-263).  `buf` is owned by the library and valid until the next
- * sdrx_process*()/sdrx_destroy().  Not invoked for an empty payload (zmqpublisher.cpp:88). */
+ * sdrx_process*() / sdrx_wait() / sdrx_fetch() / sdrx_destroy() -- libzmq copies on zmq_send
+ * (zmqpublisher.cpp:91-93), so the reference's publisher needs it no longer than the callback.
+ * Not invoked for an empty payload (zmqpublisher.cpp:88). */
 typedef void (*sdrx_publish_fn)(void *user, const char topic[5], uint32_t sample_rate, const void *buf,
                                 uint32_t len_bytes);
 
@@ -82,6 +84,11 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
  *   "keep_prequant" 1: also keep the pre-quantisation float `usb*gain*32768` per leaf
  *            (parity tests; sdrx_get_prequant).   default 0
  *   "segments" n: force n time-segments per VFO-frame in the decimation kernel (0 = auto).
+ *   "pipeline" 1 (default): the leaf tail of a frame (late decimation, USB demodulation,
+ *            compress) runs on a second HIP stream, so that it overlaps the mix/decimate launches
+ *            of the NEXT frame when frames are queued back to back (sdrx_submit* or
+ *            sdrx_process_device without a fetch in between); ordering between the two streams
+ *            is by HIP events, results are bit-identical.  0: everything on one stream in order.
  *   "dc_blocked_scan" 0|1 (default 0): how sdrx_process_u8 removes the DC bias.  0 = the
  *                 reference's sequentially rounded fp32 recurrence, bit for bit (one wave,
  *                 ~1.7 ms per 384 000-sample frame).  1 = the same linear filter as a blocked
@@ -119,8 +126,30 @@ int sdrx_process_device(sdrx_ctx *ctx, const void *dev_iq, int n_complex);
 int sdrx_fetch(sdrx_ctx *ctx);
 int sdrx_sync(sdrx_ctx *ctx);
 /* Run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the context's
- * own; NULL restores the default. */
+ * own; NULL restores the default.  The frame is consumed on that stream (work the caller queues on
+ * it after sdrx_process_device may overwrite the frame); the leaf tail may run on a stream of the
+ * library's own (option "pipeline"), which sdrx_sync / sdrx_fetch / sdrx_wait also wait for. */
 int sdrx_set_stream(sdrx_ctx *ctx, void *hip_stream);
+
+/* ---- pipelined per-frame interface ("optional async submit/wait pair") ---------------
+ * sdrx_submit* enqueue one frame and return at once: host -> device copy of the frame (staged through
+ * pinned memory of the library's own: `iq` is borrowed for the duration of the call only, like the
+ * argument of sdrj::demodData), kernels, and the device -> host copy of that frame's payloads on a
+ * copy stream -- which therefore overlaps the kernels of the next frame.  sdrx_wait delivers the
+ * OLDEST frame not yet delivered: it blocks until that frame's payloads are in host memory, then
+ * runs the publish callback for every leaf in the reference's order (= ZmqPublisher::publish per
+ * leaf, vfo.cpp:426-453); afterwards sdrx_get_output serves that frame.  At most
+ * SDRX_MAX_IN_FLIGHT frames may be submitted and not yet delivered (SDRX_ESTATE otherwise).
+ * The steady state of a streaming host is  submit(f+1); wait() -> f;  i.e. one frame of latency in
+ * exchange for PCIe and kernels running concurrently.  sdrx_process* are submit + wait of one frame.
+ * While frames are in flight the synchronous calls (sdrx_process*, sdrx_fetch, sdrx_get_*) return
+ * SDRX_ESTATE. */
+#define SDRX_MAX_IN_FLIGHT 2
+int sdrx_submit(sdrx_ctx *ctx, const float *iq, int n_complex);
+int sdrx_submit_u8(sdrx_ctx *ctx, const uint8_t *iq_bytes, int n_complex, int correct_dc);
+int sdrx_submit_device(sdrx_ctx *ctx, const void *dev_iq, int n_complex);
+int sdrx_wait(sdrx_ctx *ctx);
+int sdrx_in_flight(sdrx_ctx *ctx); /* >= 0: frames submitted and not yet delivered; < 0: error */
 
 /* ---- results -------------------------------------------------------------------------------- */
 /* Payload of leaf `id` after the last frame: int16 audio (USB leaf) or packed int8 IQ
@@ -150,6 +179,8 @@ typedef struct sdrx_stats {
     int64_t vfo_samples_per_frame;       /* sum of n_in over all VFOs                        */
     int64_t device_bytes;                /* HBM allocated by this context                    */
     int64_t frames;                      /* frames processed so far                          */
+    int64_t mix_chunks_per_frame;        /* 1024-sample chunks the k_mix_decimate waves walk  */
+                                         /*   per frame, warm-up chunks of segments included  */
 } sdrx_stats;
 int sdrx_get_stats(sdrx_ctx *ctx, sdrx_stats *out);
 /* Per-kernel GPU time from HIP events recorded on the launch stream.  enable=1 brackets every

@@ -36,7 +36,7 @@ class StatsC(C.Structure):
     _fields_ = [
         ("n_vfos", C.c_int32), ("n_leaves", C.c_int32), ("n_levels", C.c_int32), ("exact", C.c_int32),
         ("algorithmic_bytes_per_frame", C.c_int64), ("vfo_samples_per_frame", C.c_int64),
-        ("device_bytes", C.c_int64), ("frames", C.c_int64),
+        ("device_bytes", C.c_int64), ("frames", C.c_int64), ("mix_chunks_per_frame", C.c_int64),
     ]
 
 
@@ -56,6 +56,11 @@ SYMBOLS = {
     "sdrx_process": (_i, [_vp, _vp, _i]),
     "sdrx_process_u8": (_i, [_vp, _vp, _i, _i]),
     "sdrx_process_device": (_i, [_vp, _vp, _i]),
+    "sdrx_submit": (_i, [_vp, _vp, _i]),
+    "sdrx_submit_u8": (_i, [_vp, _vp, _i, _i]),
+    "sdrx_submit_device": (_i, [_vp, _vp, _i]),
+    "sdrx_wait": (_i, [_vp]),
+    "sdrx_in_flight": (_i, [_vp]),
     "sdrx_fetch": (_i, [_vp]),
     "sdrx_sync": (_i, [_vp]),
     "sdrx_set_stream": (_i, [_vp, _vp]),

@@ -999,7 +999,7 @@ __global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfo
         float *prequant;
         float gain;
         int H, n, nlpf, tile;
-    } D = {Dp->hnz, Dp->lpf_pad, Dp->pay, Dp->prequant, Dp->gain, Dp->H, Dp->n, Dp->nlpf, Dp->tile};
+    } D = {Dp->hnz, Dp->lpf_pad, Dp->pay[par], Dp->prequant, Dp->gain, Dp->H, Dp->n, Dp->nlpf, Dp->tile};
     const float2 *sbase = Dp->s[par];
     float2 *snext = Dp->s_next[par];
     const int m0 = blk * D.tile;
@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(256) void k_compress(const K3Vfo *__restrict__ vfos
     struct {
         signed char *pay;
         int n, cstyle, scalecomp;
-    } D = {Dp->pay, Dp->n, Dp->cstyle, Dp->scalecomp};
+    } D = {Dp->pay[par], Dp->n, Dp->cstyle, Dp->scalecomp};
     const float2 *z = Dp->s[par];
     for (int i = blk * 4096 + threadIdx.x; i < min(D.n, (blk + 1) * 4096); i += 256) {
         const float2 v = gld2(z + i);

@@ -31,7 +31,7 @@
 using namespace sdrx;
 
 static_assert(sizeof(sdrx_vfo_desc) == 56 && offsetof(sdrx_vfo_desc, topic) == 48, "sdrx_vfo_desc ABI layout");
-static_assert(sizeof(sdrx_stats) == 48, "sdrx_stats ABI layout");
+static_assert(sizeof(sdrx_stats) == 56, "sdrx_stats ABI layout");
 
 namespace {
 
@@ -91,15 +91,30 @@ struct sdrx_ctx {
     std::string err;
     std::vector<Node> nodes;
     bool finalized = false;
-    int opt_exact = 1, opt_prequant = 0, opt_segments = 0, opt_dc_blocked = 0;
+    int opt_exact = 1, opt_prequant = 0, opt_segments = 0, opt_dc_blocked = 0, opt_pipeline = 1;
     sdrx_publish_fn cb = nullptr;
     void *cb_user = nullptr;
 
-    hipStream_t own_stream = nullptr, stream = nullptr;
+    // Streams.  `stream` (the context's own or the caller's) carries the ingest and the
+    // mix/decimate launches of every tree level; the leaf tail of a frame runs on `tail_stream`
+    // when option "pipeline" is on, so that it overlaps the next frame's levels; payloads leave on
+    // `copy_stream` for frames that came in through sdrx_submit*.  Cross-stream order is by the
+    // per-parity events below (measured on this runtime, tools/event_probe.hip: a record costs its
+    // stream ~3-5 us, a wait on an event that completed long ago ~2.5 us, a tight hop ~11 us).
+    hipStream_t own_stream = nullptr, stream = nullptr, tail_stream = nullptr, copy_stream = nullptr;
+    hipEvent_t ev_levels[2] = {nullptr, nullptr}; // levels of frame f done (recorded on `stream`)
+    hipEvent_t ev_tail[2] = {nullptr, nullptr};   // tail of frame f done (recorded on the tail's stream)
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}; // payloads of frame f are in h_pay[f & 1]
+    bool tail_recorded[2] = {false, false};
     unsigned char *arena = nullptr;
     size_t arena_bytes = 0;
-    unsigned char *d_pay = nullptr, *h_pay = nullptr;
+    unsigned char *d_pay[2] = {nullptr, nullptr}, *h_pay[2] = {nullptr, nullptr}; // per frame parity
     size_t pay_bytes = 0;
+    unsigned char *h_in[2] = {nullptr, nullptr}; // pinned staging of host-fed frames, per frame parity
+    size_t h_in_bytes = 0;
+    int in_flight = 0;               // frames submitted (sdrx_submit*) and not yet delivered (sdrx_wait)
+    unsigned long long delivered = 0; // index of the next frame sdrx_wait delivers
+    int host_slot = -1;              // which h_pay holds the payloads sdrx_get_output serves
     float2 *d_raw = nullptr;       // staging for host-fed frames (natural order)
     float2 *d_raw_tiled = nullptr; // the raw frame in tile layout: input of the parent-less VFOs
     int last_raw = -1;             // how the last frame reached level 0 (kRaw*; -1: caller-owned device memory)
@@ -119,7 +134,7 @@ struct sdrx_ctx {
     std::vector<int> publish_order;
     unsigned long long frame_no = 0;
     bool pending_fetch = false;
-    int64_t alg_bytes = 0, vfo_samples = 0;
+    int64_t alg_bytes = 0, vfo_samples = 0, mix_chunks = 0;
     int n_levels = 0;
 
     bool timing = false;
@@ -188,8 +203,9 @@ hipEvent_t get_event(sdrx_ctx *c)
         c->event_pool.pop_back();
         return e;
     }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess)
+        return nullptr; // the launch is then simply not timed
     return e;
 }
 
@@ -208,11 +224,12 @@ void drain_events(sdrx_ctx *c)
     c->pending_events.clear();
 }
 
-struct Bracket { // RAII: event pair around one launch when timing is on
+struct Bracket { // RAII: event pair around one launch when timing is on, on the launch's stream
     sdrx_ctx *c;
+    hipStream_t st;
     TimedEvent te{};
     bool on;
-    Bracket(sdrx_ctx *ctx, int kind, int64_t bytes) : c(ctx), on(ctx->timing)
+    Bracket(sdrx_ctx *ctx, hipStream_t stream, int kind, int64_t bytes) : c(ctx), st(stream), on(ctx->timing)
     {
         if (!on)
             return;
@@ -220,26 +237,47 @@ struct Bracket { // RAII: event pair around one launch when timing is on
         te.bytes = bytes;
         te.a = get_event(c);
         te.b = get_event(c);
-        (void)hipEventRecord(te.a, c->stream);
+        if (!te.a || !te.b) {
+            on = false;
+            return;
+        }
+        (void)hipEventRecord(te.a, st);
     }
     ~Bracket()
     {
         if (!on)
             return;
-        (void)hipEventRecord(te.b, c->stream);
+        (void)hipEventRecord(te.b, st);
         c->pending_events.push_back(te);
     }
 };
 
+// One frame: [wait for the tail of frame f-2] -> ingest -> one k_mix_decimate launch per tree level on
+// `stream`; then the leaf tail (late decimation, demodulation, compress) -- on `tail_stream` behind an
+// event when the pipeline option is on, so that it runs beside the NEXT frame's levels -- and, for a
+// frame that came through sdrx_submit*, the payload copy on `copy_stream` behind the tail.
+//
+// What makes the two-stream form safe (frame f, parity p = f & 1):
+//   * the leaf streams of parity p are written by the levels of f and read by the tail of f: the tail
+//     waits for ev_levels[p]; their next writer is frame f+2, whose levels wait for ev_tail[p] first;
+//   * the history prefix of the parity-(p^1) leaf streams is written by the tail of f and read by the
+//     tail of f+1: same stream, in order (the levels of f+1 write only the data part behind it);
+//   * half-band state, NCO tables and the parents' streams are touched by the levels only;
+//   * d_pay[p] is written by the tail of f and read by the copy of f; its next writer is the tail of
+//     f+2, which the host does not submit before frame f was delivered (SDRX_MAX_IN_FLIGHT = 2).
 template <bool EXACT>
-int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode)
+int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode, bool egress)
 {
     const K1Vfo *k1 = reinterpret_cast<const K1Vfo *>(c->arena + c->off_k1vfo);
+    const int p = (int)(c->frame_no & 1ull);
+    const bool pipe = c->opt_pipeline != 0;
+    if (pipe && c->tail_recorded[p])
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_tail[p], 0));
     // A few parent-less VFOs (the reference's 2-3 mains) read the caller's frame as it is; a wide
     // level 0 (the flat workloads) is bandwidth bound and wants coalesced reads: one layout pass
     // natural order -> tile layout first.
     if (raw_mode != kRawTiled && !c->root_direct) {
-        Bracket b(c, KIND_INGEST, 0);
+        Bracket b(c, c->stream, KIND_INGEST, 0);
         const int n_pairs = c->root_frame / 2;
         if (raw_mode == kRawF32)
             hipLaunchKernelGGL(k_ingest_f32, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream,
@@ -250,7 +288,7 @@ int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode)
         raw_mode = kRawTiled;
     }
     for (const Launch1 &L : c->l1) {
-        Bracket b(c, L.kind, L.alg_bytes);
+        Bracket b(c, c->stream, L.kind, L.alg_bytes);
         const K1Work *w = reinterpret_cast<const K1Work *>(c->arena + L.off_work);
         if (L.level == 0)
             hipLaunchKernelGGL((k_mix_decimate<EXACT, 0>), dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1, w, c->frame_no, raw, raw_mode);
@@ -258,33 +296,106 @@ int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode)
             hipLaunchKernelGGL((k_mix_decimate<EXACT, 1>), dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1, w, c->frame_no,
                                (const void *)nullptr, kRawTiled);
     }
+    hipStream_t ts = pipe ? c->tail_stream : c->stream;
+    if (pipe) {
+        HIPCHK(c, hipEventRecord(c->ev_levels[p], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(ts, c->ev_levels[p], 0));
+    }
     for (const LaunchB &L : c->lb) {
-        Bracket b(c, L.kind, L.alg_bytes);
+        Bracket b(c, ts, L.kind, L.alg_bytes);
         const dim3 grid(L.n_blocks);
         const BlockWork *w = reinterpret_cast<const BlockWork *>(c->arena + L.off_work);
         if (L.kind == KIND_LATE_DEC && c->late4)
             if (c->late4_r == 2)
-                hipLaunchKernelGGL((k_late_decimate4<EXACT, 2>), grid, dim3(64), L.lds_bytes, c->stream,
+                hipLaunchKernelGGL((k_late_decimate4<EXACT, 2>), grid, dim3(64), L.lds_bytes, ts,
                                    reinterpret_cast<const K2aVfo *>(c->arena + L.off_desc), w, c->frame_no);
             else
-                hipLaunchKernelGGL((k_late_decimate4<EXACT, 4>), grid, dim3(64), L.lds_bytes, c->stream,
+                hipLaunchKernelGGL((k_late_decimate4<EXACT, 4>), grid, dim3(64), L.lds_bytes, ts,
                                    reinterpret_cast<const K2aVfo *>(c->arena + L.off_desc), w, c->frame_no);
         else if (L.kind == KIND_LATE_DEC)
-            hipLaunchKernelGGL(k_late_decimate<EXACT>, grid, dim3(256), L.lds_bytes, c->stream,
+            hipLaunchKernelGGL(k_late_decimate<EXACT>, grid, dim3(256), L.lds_bytes, ts,
                                reinterpret_cast<const K2aVfo *>(c->arena + L.off_desc), w, c->frame_no);
         else if (L.kind == KIND_DEMOD)
-            hipLaunchKernelGGL(k_usb_demod<EXACT>, grid, dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(k_usb_demod<EXACT>, grid, dim3(256), 0, ts,
                                reinterpret_cast<const K2Vfo *>(c->arena + L.off_desc), w, c->frame_no);
         else
-            hipLaunchKernelGGL(k_compress, grid, dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(k_compress, grid, dim3(256), 0, ts,
                                reinterpret_cast<const K3Vfo *>(c->arena + L.off_desc), w, c->frame_no);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(c, SDRX_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    if (pipe || egress) {
+        HIPCHK(c, hipEventRecord(c->ev_tail[p], ts));
+        c->tail_recorded[p] = pipe;
+    }
+    if (egress) {
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_tail[p], 0));
+        HIPCHK(c, hipMemcpyAsync(c->h_pay[p], c->d_pay[p], c->pay_bytes, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->ev_copied[p], c->copy_stream));
+        c->in_flight++;
+    }
     c->frame_no++;
-    c->pending_fetch = true;
+    c->pending_fetch = !egress;
     return SDRX_OK;
+}
+
+// every stream of the context is idle afterwards
+int drain(sdrx_ctx *c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->tail_stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    drain_events(c);
+    return SDRX_OK;
+}
+
+// vfo::transmitData for every leaf, in the reference's order (vfo.cpp:426-453, sdrj.cpp:288-294)
+void publish_all(sdrx_ctx *c, int slot)
+{
+    c->host_slot = slot;
+    if (!c->cb)
+        return;
+    for (int i : c->publish_order) {
+        const Node &n = c->nodes[(size_t)i];
+        // USB leaves always publish; an IQ leaf only with a topic; ZmqPublisher::publish sends
+        // nothing for len 0 (zmqpublisher.cpp:88).
+        if (n.pay_len == 0)
+            continue;
+        if (!n.d.demod_usb && n.d.topic[0] == 0)
+            continue;
+        char topic[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < 5 && n.d.topic[k]; ++k)
+            topic[k] = n.d.topic[k];
+        c->cb(c->cb_user, topic, n.rate, c->h_pay[slot] + n.pay_off, n.pay_len);
+    }
+}
+
+void free_device_state(sdrx_ctx *c)
+{
+    auto dfree = [](auto *&p) {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+    };
+    auto hfree = [](unsigned char *&p) {
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+    };
+    dfree(c->arena);
+    for (int p = 0; p < 2; ++p) {
+        dfree(c->d_pay[p]);
+        hfree(c->h_pay[p]);
+        hfree(c->h_in[p]);
+    }
+    c->h_in_bytes = 0;
+    dfree(c->d_raw);
+    dfree(c->d_raw_u8);
+    dfree(c->d_raw_tiled);
+    dfree(c->d_dc_state);
+    dfree(c->d_dc_tab);
+    c->raw_cap = 0;
 }
 
 int ensure_raw(sdrx_ctx *c, size_t n_complex)
@@ -335,6 +446,16 @@ int sdrx_create(sdrx_ctx **out, int device)
         return fail(nullptr, SDRX_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     c->stream = c->own_stream;
+    bool ok = hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int p = 0; p < 2 && ok; ++p)
+        ok = hipEventCreateWithFlags(&c->ev_levels[p], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_tail[p], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_copied[p], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        sdrx_destroy(c);
+        return fail(nullptr, SDRX_EHIP, "sdrx_create: could not create the streams / events of the context");
+    }
     *out = c;
     return SDRX_OK;
 }
@@ -344,28 +465,23 @@ int sdrx_destroy(sdrx_ctx *c)
     if (!c)
         return SDRX_EINVAL;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    if (c->tail_stream)
+        (void)hipStreamSynchronize(c->tail_stream);
+    if (c->copy_stream)
+        (void)hipStreamSynchronize(c->copy_stream);
     drain_events(c);
     for (hipEvent_t e : c->event_pool)
         (void)hipEventDestroy(e);
-    if (c->arena)
-        (void)hipFree(c->arena);
-    if (c->d_pay)
-        (void)hipFree(c->d_pay);
-    if (c->h_pay)
-        (void)hipHostFree(c->h_pay);
-    if (c->d_raw)
-        (void)hipFree(c->d_raw);
-    if (c->d_raw_u8)
-        (void)hipFree(c->d_raw_u8);
-    if (c->d_raw_tiled)
-        (void)hipFree(c->d_raw_tiled);
-    if (c->d_dc_state)
-        (void)hipFree(c->d_dc_state);
-    if (c->d_dc_tab)
-        (void)hipFree(c->d_dc_tab);
-    if (c->own_stream)
-        (void)hipStreamDestroy(c->own_stream);
+    for (int p = 0; p < 2; ++p)
+        for (hipEvent_t e : {c->ev_levels[p], c->ev_tail[p], c->ev_copied[p]})
+            if (e)
+                (void)hipEventDestroy(e);
+    free_device_state(c);
+    for (hipStream_t st : {c->own_stream, c->tail_stream, c->copy_stream})
+        if (st)
+            (void)hipStreamDestroy(st);
     delete c;
     return SDRX_OK;
 }
@@ -384,6 +500,8 @@ int sdrx_set_option(sdrx_ctx *c, const char *name, int value)
         c->opt_segments = value < 0 ? 0 : value;
     else if (!strcmp(name, "dc_blocked_scan"))
         c->opt_dc_blocked = value != 0;
+    else if (!strcmp(name, "pipeline"))
+        c->opt_pipeline = value != 0;
     else
         return fail(c, SDRX_EINVAL, "unknown option '%s'", name);
     return SDRX_OK;
@@ -425,6 +543,8 @@ int sdrx_set_publish_callback(sdrx_ctx *c, sdrx_publish_fn fn, void *user)
     return SDRX_OK;
 }
 
+static int finalize_impl(sdrx_ctx *c);
+
 int sdrx_finalize(sdrx_ctx *c)
 {
     if (!c)
@@ -434,6 +554,19 @@ int sdrx_finalize(sdrx_ctx *c)
     if (c->nodes.empty())
         return fail(c, SDRX_ESTATE, "sdrx_finalize: no VFOs");
     HIPCHK(c, hipSetDevice(c->device));
+    const int rc = finalize_impl(c);
+    if (rc != SDRX_OK) { // nothing of a half-built tree stays behind: a later call starts clean
+        (void)hipStreamSynchronize(c->stream);
+        free_device_state(c);
+        c->l1.clear();
+        c->lb.clear();
+        c->publish_order.clear();
+    }
+    return rc;
+}
+
+static int finalize_impl(sdrx_ctx *c)
+{
     const int N = (int)c->nodes.size();
 
     // ---- per-node derived quantities: everything vfo::init computes (vfo.cpp:60-176)
@@ -527,6 +660,7 @@ int sdrx_finalize(sdrx_ctx *c)
     size_t pay = 0;
     c->alg_bytes = 0;
     c->vfo_samples = 0;
+    c->mix_chunks = 0;
     for (int i = 0; i < N; ++i) {
         Node &n = c->nodes[(size_t)i];
         const sdrx_vfo_desc &d = n.d;
@@ -645,6 +779,7 @@ int sdrx_finalize(sdrx_ctx *c)
                 }
             }
             works[(size_t)n.level].push_back(w);
+            c->mix_chunks += (w.s_end - w.s_begin + kChunk - 1) / kChunk;
             first_out = w.s_end;
         }
     }
@@ -767,10 +902,12 @@ int sdrx_finalize(sdrx_ctx *c)
     HIPCHK(c, hipMalloc(&c->arena, c->arena_bytes));
     HIPCHK(c, hipMemsetAsync(c->arena, 0, c->arena_bytes, c->stream));
     c->pay_bytes = std::max<size_t>(pay, 64);
-    HIPCHK(c, hipMalloc(&c->d_pay, c->pay_bytes));
-    HIPCHK(c, hipMemsetAsync(c->d_pay, 0, c->pay_bytes, c->stream));
-    HIPCHK(c, hipHostMalloc(&c->h_pay, c->pay_bytes, hipHostMallocDefault));
-    memset(c->h_pay, 0, c->pay_bytes);
+    for (int p = 0; p < 2; ++p) {
+        HIPCHK(c, hipMalloc(&c->d_pay[p], c->pay_bytes));
+        HIPCHK(c, hipMemsetAsync(c->d_pay[p], 0, c->pay_bytes, c->stream));
+        HIPCHK(c, hipHostMalloc(&c->h_pay[p], c->pay_bytes, hipHostMallocDefault));
+        memset(c->h_pay[p], 0, c->pay_bytes);
+    }
 
     {
         const size_t raw_tiles = align_up((size_t)c->root_frame, kChunk) + kChunk; // (+1 tile, as for the parents' streams)
@@ -829,7 +966,8 @@ int sdrx_finalize(sdrx_ctx *c)
         }
         k.hnz = reinterpret_cast<const float *>(P(n.off_hnz));
         k.lpf_pad = n.lpf.empty() ? nullptr : reinterpret_cast<const float *>(P(n.off_lpf));
-        k.pay = reinterpret_cast<short *>(c->d_pay + n.pay_off);
+        for (int p = 0; p < 2; ++p)
+            k.pay[p] = reinterpret_cast<short *>(c->d_pay[p] + n.pay_off);
         k.prequant = (c->opt_prequant) ? reinterpret_cast<float *>(P(n.off_preq)) : nullptr;
         k.gain = n.d.gain;
         k.H = late ? n.H : n.Hx;
@@ -840,9 +978,10 @@ int sdrx_finalize(sdrx_ctx *c)
     for (size_t q = 0; q < d3.size(); ++q) {
         Node &n = c->nodes[(size_t)n3[q]];
         K3Vfo &k = d3[q];
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < 2; ++p) {
             k.s[p] = reinterpret_cast<const float2 *>(P(n.off_stream[p])) + n.Hx;
-        k.pay = reinterpret_cast<signed char *>(c->d_pay + n.pay_off);
+            k.pay[p] = reinterpret_cast<signed char *>(c->d_pay[p] + n.pay_off);
+        }
         k.n = n.n_f;
         k.cstyle = n.d.cstyle;
         k.scalecomp = n.d.scalecomp;
@@ -894,95 +1033,74 @@ int sdrx_set_stream(sdrx_ctx *c, void *s)
 {
     if (!c)
         return SDRX_EINVAL;
-    (void)hipStreamSynchronize(c->stream);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = drain(c);
+    if (rc)
+        return rc;
     c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
     return SDRX_OK;
 }
 
-int sdrx_process_device(sdrx_ctx *c, const void *dev_iq, int n_complex)
+} // extern "C"
+
+namespace {
+
+int check_frame_call(sdrx_ctx *c, const char *what, const void *ptr, int n_complex, bool sync_call)
 {
     if (!c)
         return SDRX_EINVAL;
+    if (!ptr)
+        return fail(c, SDRX_EINVAL, "%s: null frame pointer", what);
     if (!c->finalized)
-        return fail(c, SDRX_ESTATE, "sdrx_process before sdrx_finalize");
+        return fail(c, SDRX_ESTATE, "%s before sdrx_finalize", what);
     if (n_complex != c->root_frame)
         return fail(c, SDRX_EINVAL, "frame of %d samples, VFOs were initialised for %d (vfo::init samplesPerBuffer)", n_complex,
                     c->root_frame);
-    if (!dev_iq)
-        return fail(c, SDRX_EINVAL, "null frame pointer");
+    if (sync_call && c->in_flight > 0)
+        return fail(c, SDRX_ESTATE, "%s: %d submitted frame(s) not yet delivered -- call sdrx_wait first", what, c->in_flight);
+    if (!sync_call && c->in_flight >= SDRX_MAX_IN_FLIGHT)
+        return fail(c, SDRX_ESTATE, "%s: %d frames in flight -- call sdrx_wait before submitting another", what, c->in_flight);
     HIPCHK(c, hipSetDevice(c->device));
-    c->last_raw = -1;
-    return c->opt_exact ? enqueue_frame<true>(c, dev_iq, kRawF32) : enqueue_frame<false>(c, dev_iq, kRawF32);
-}
-
-int sdrx_sync(sdrx_ctx *c)
-{
-    if (!c)
-        return SDRX_EINVAL;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    drain_events(c);
     return SDRX_OK;
 }
 
-int sdrx_fetch(sdrx_ctx *c)
+// host frame -> the library's pinned staging buffer of this frame parity -> device.  The buffer's
+// previous user is frame f-2, which has been delivered (or fetched), so its copy is long done.
+int stage_host_frame(sdrx_ctx *c, const void *src, size_t bytes, void *dst_dev)
 {
-    if (!c)
-        return SDRX_EINVAL;
-    if (!c->finalized)
-        return fail(c, SDRX_ESTATE, "sdrx_fetch before sdrx_finalize");
-    HIPCHK(c, hipMemcpyAsync(c->h_pay, c->d_pay, c->pay_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    drain_events(c);
-    c->pending_fetch = false;
-    if (c->cb) {
-        for (int i : c->publish_order) {
-            const Node &n = c->nodes[(size_t)i];
-            // vfo::transmitData (vfo.cpp:426-453): USB leaves always publish; an IQ leaf only with a
-            // topic; ZmqPublisher::publish sends nothing for len 0 (zmqpublisher.cpp:88).
-            if (n.pay_len == 0)
-                continue;
-            if (!n.d.demod_usb && n.d.topic[0] == 0)
-                continue;
-            char topic[5] = {0, 0, 0, 0, 0};
-            for (int k = 0; k < 5 && n.d.topic[k]; ++k)
-                topic[k] = n.d.topic[k];
-            c->cb(c->cb_user, topic, n.rate, c->h_pay + n.pay_off, n.pay_len);
+    const int p = (int)(c->frame_no & 1ull);
+    if (c->h_in_bytes < (size_t)c->root_frame * sizeof(float2)) {
+        for (int q = 0; q < 2; ++q) {
+            if (c->h_in[q])
+                (void)hipHostFree(c->h_in[q]);
+            c->h_in[q] = nullptr;
+            HIPCHK(c, hipHostMalloc(&c->h_in[q], (size_t)c->root_frame * sizeof(float2), hipHostMallocDefault));
         }
+        c->h_in_bytes = (size_t)c->root_frame * sizeof(float2);
     }
+    if (c->pending_fetch) // frames queued by sdrx_process_device and never fetched may still be reading it
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(c->h_in[p], src, bytes);
+    HIPCHK(c, hipMemcpyAsync(dst_dev, c->h_in[p], bytes, hipMemcpyHostToDevice, c->stream));
     return SDRX_OK;
 }
 
-int sdrx_process(sdrx_ctx *c, const float *iq, int n_complex)
+int enqueue_f32(sdrx_ctx *c, const float *iq, int n_complex, bool egress)
 {
-    if (!c || !iq)
-        return SDRX_EINVAL;
-    if (!c->finalized)
-        return fail(c, SDRX_ESTATE, "sdrx_process before sdrx_finalize");
-    HIPCHK(c, hipSetDevice(c->device));
     int rc = ensure_raw(c, (size_t)c->root_frame);
     if (rc)
         return rc;
-    if (n_complex != c->root_frame)
-        return fail(c, SDRX_EINVAL, "frame of %d samples, VFOs were initialised for %d (vfo::init samplesPerBuffer)", n_complex,
-                    c->root_frame);
-    HIPCHK(c, hipMemcpyAsync(c->d_raw, iq, (size_t)n_complex * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-    rc = sdrx_process_device(c, c->d_raw, n_complex);
+    rc = stage_host_frame(c, iq, (size_t)n_complex * sizeof(float2), c->d_raw);
     if (rc)
         return rc;
-    c->last_raw = kRawF32;
-    return sdrx_fetch(c);
+    rc = c->opt_exact ? enqueue_frame<true>(c, c->d_raw, kRawF32, egress) : enqueue_frame<false>(c, c->d_raw, kRawF32, egress);
+    if (rc == SDRX_OK)
+        c->last_raw = kRawF32;
+    return rc;
 }
 
-int sdrx_process_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correct_dc)
+int enqueue_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correct_dc, bool egress)
 {
-    if (!c || !bytes)
-        return SDRX_EINVAL;
-    if (!c->finalized)
-        return fail(c, SDRX_ESTATE, "sdrx_process_u8 before sdrx_finalize");
-    if (n_complex != c->root_frame)
-        return fail(c, SDRX_EINVAL, "frame of %d samples, VFOs were initialised for %d (vfo::init samplesPerBuffer)", n_complex,
-                    c->root_frame);
-    HIPCHK(c, hipSetDevice(c->device));
     int rc = ensure_raw(c, (size_t)c->root_frame);
     if (rc)
         return rc;
@@ -990,7 +1108,9 @@ int sdrx_process_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correc
         HIPCHK(c, hipMalloc(&c->d_dc_state, 4 * sizeof(float)));
         HIPCHK(c, hipMemsetAsync(c->d_dc_state, 0, 4 * sizeof(float), c->stream)); // `static cpx_typef avept=0`, sdrj.cpp:279
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_raw_u8, bytes, (size_t)n_complex * 2, hipMemcpyHostToDevice, c->stream));
+    rc = stage_host_frame(c, bytes, (size_t)n_complex * 2, c->d_raw_u8);
+    if (rc)
+        return rc;
     int mode = kRawU8;
     const int nchunks = (n_complex + kChunk - 1) / kChunk;
     if (correct_dc && c->opt_dc_blocked && !c->d_dc_tab) {
@@ -1008,12 +1128,12 @@ int sdrx_process_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correc
         HIPCHK(c, hipMemcpy(c->d_dc_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if (correct_dc && !c->opt_dc_blocked) {
-        Bracket b(c, KIND_INGEST, 0);
+        Bracket b(c, c->stream, KIND_INGEST, 0);
         hipLaunchKernelGGL(k_ingest_u8_dc, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(c->d_raw_u8),
                            reinterpret_cast<float4 *>(c->d_raw_tiled), n_complex, c->d_dc_state);
         mode = kRawTiled;
     } else if (correct_dc) {
-        Bracket b(c, KIND_INGEST, 0);
+        Bracket b(c, c->stream, KIND_INGEST, 0);
         const int par = (int)(c->dc_frames++ & 1ull);
         double2 *sums = reinterpret_cast<double2 *>(c->d_dc_tab + c->dc_tab_sums);
         hipLaunchKernelGGL(k_dc_block_sums, dim3(nchunks), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(c->d_raw_u8), n_complex,
@@ -1023,11 +1143,113 @@ int sdrx_process_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correc
                            c->d_dc_tab, sums);
         mode = kRawTiled;
     }
-    rc = c->opt_exact ? enqueue_frame<true>(c, c->d_raw_u8, mode) : enqueue_frame<false>(c, c->d_raw_u8, mode);
+    rc = c->opt_exact ? enqueue_frame<true>(c, c->d_raw_u8, mode, egress) : enqueue_frame<false>(c, c->d_raw_u8, mode, egress);
+    if (rc == SDRX_OK)
+        c->last_raw = mode;
+    return rc;
+}
+
+} // namespace
+
+extern "C" {
+
+int sdrx_process_device(sdrx_ctx *c, const void *dev_iq, int n_complex)
+{
+    int rc = check_frame_call(c, "sdrx_process_device", dev_iq, n_complex, true);
     if (rc)
         return rc;
-    c->last_raw = mode;
-    return sdrx_fetch(c);
+    c->last_raw = -1;
+    return c->opt_exact ? enqueue_frame<true>(c, dev_iq, kRawF32, false) : enqueue_frame<false>(c, dev_iq, kRawF32, false);
+}
+
+int sdrx_submit_device(sdrx_ctx *c, const void *dev_iq, int n_complex)
+{
+    int rc = check_frame_call(c, "sdrx_submit_device", dev_iq, n_complex, false);
+    if (rc)
+        return rc;
+    c->last_raw = -1;
+    return c->opt_exact ? enqueue_frame<true>(c, dev_iq, kRawF32, true) : enqueue_frame<false>(c, dev_iq, kRawF32, true);
+}
+
+int sdrx_submit(sdrx_ctx *c, const float *iq, int n_complex)
+{
+    int rc = check_frame_call(c, "sdrx_submit", iq, n_complex, false);
+    return rc ? rc : enqueue_f32(c, iq, n_complex, true);
+}
+
+int sdrx_submit_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correct_dc)
+{
+    int rc = check_frame_call(c, "sdrx_submit_u8", bytes, n_complex, false);
+    return rc ? rc : enqueue_u8(c, bytes, n_complex, correct_dc, true);
+}
+
+int sdrx_in_flight(sdrx_ctx *c) { return c ? c->in_flight : SDRX_EINVAL; }
+
+int sdrx_wait(sdrx_ctx *c)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    if (c->in_flight <= 0)
+        return fail(c, SDRX_ESTATE, "sdrx_wait: no submitted frame is in flight");
+    HIPCHK(c, hipSetDevice(c->device));
+    const unsigned long long f = c->frame_no - (unsigned long long)c->in_flight; // the oldest undelivered frame
+    const int p = (int)(f & 1ull);
+    HIPCHK(c, hipEventSynchronize(c->ev_copied[p]));
+    c->in_flight--;
+    c->delivered = f + 1;
+    if (c->in_flight == 0)
+        drain_events(c);
+    publish_all(c, p);
+    return SDRX_OK;
+}
+
+int sdrx_sync(sdrx_ctx *c)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    return drain(c);
+}
+
+int sdrx_fetch(sdrx_ctx *c)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    if (!c->finalized)
+        return fail(c, SDRX_ESTATE, "sdrx_fetch before sdrx_finalize");
+    if (c->in_flight > 0)
+        return fail(c, SDRX_ESTATE, "sdrx_fetch: %d submitted frame(s) not yet delivered -- call sdrx_wait", c->in_flight);
+    if (c->frame_no == 0)
+        return fail(c, SDRX_ESTATE, "sdrx_fetch: no frame processed yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int p = (int)((c->frame_no - 1) & 1ull); // the last frame's payloads
+    hipStream_t ts = c->opt_pipeline ? c->tail_stream : c->stream;
+    if (c->pending_fetch)
+        HIPCHK(c, hipMemcpyAsync(c->h_pay[p], c->d_pay[p], c->pay_bytes, hipMemcpyDeviceToHost, ts));
+    int rc = drain(c);
+    if (rc)
+        return rc;
+    c->pending_fetch = false;
+    publish_all(c, p);
+    return SDRX_OK;
+}
+
+int sdrx_process(sdrx_ctx *c, const float *iq, int n_complex)
+{
+    int rc = check_frame_call(c, "sdrx_process", iq, n_complex, true);
+    if (rc)
+        return rc;
+    rc = enqueue_f32(c, iq, n_complex, true);
+    return rc ? rc : sdrx_wait(c);
+}
+
+int sdrx_process_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correct_dc)
+{
+    int rc = check_frame_call(c, "sdrx_process_u8", bytes, n_complex, true);
+    if (rc)
+        return rc;
+    rc = enqueue_u8(c, bytes, n_complex, correct_dc, true);
+    return rc ? rc : sdrx_wait(c);
 }
 
 int sdrx_get_output(sdrx_ctx *c, int id, const void **buf, uint32_t *len, uint32_t *rate)
@@ -1039,13 +1261,16 @@ int sdrx_get_output(sdrx_ctx *c, int id, const void **buf, uint32_t *len, uint32
     const Node &n = c->nodes[(size_t)id];
     if (!n.leaf)
         return fail(c, SDRX_EINVAL, "vfo %d has children and publishes nothing (vfo.cpp:253-266)", id);
-    if (c->pending_fetch) {
+    if (c->pending_fetch) { // frames queued with sdrx_process_device: bring the last one's payloads over
         int rc = sdrx_fetch(c);
         if (rc)
             return rc;
     }
-    if (buf)
-        *buf = c->h_pay + n.pay_off;
+    if (buf) {
+        if (c->host_slot < 0)
+            return fail(c, SDRX_ESTATE, "sdrx_get_output: no frame has been delivered yet");
+        *buf = c->h_pay[c->host_slot] + n.pay_off;
+    }
     if (len)
         *len = n.pay_len;
     if (rate)
@@ -1063,7 +1288,8 @@ int sdrx_get_raw(sdrx_ctx *c, float *out, int max_complex, int *n_ret)
         return fail(c, SDRX_ESTATE, "sdrx_get_raw: the last frame was caller-owned device memory (sdrx_process_device)");
     HIPCHK(c, hipSetDevice(c->device));
     const int n = std::min(max_complex, c->root_frame);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = drain(c))
+        return rc;
     if (c->last_raw == kRawF32) {
         HIPCHK(c, hipMemcpy(out, c->d_raw, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
     } else if (c->last_raw == kRawU8) { // floats[b] = b - 127, jonti/sdr.cpp:43-49
@@ -1096,7 +1322,9 @@ int sdrx_get_stream(sdrx_ctx *c, int id, float *out, int max_complex, int *n_ret
     const Node &n = c->nodes[(size_t)id];
     const int par = (int)((c->frame_no - 1) & 1ull);
     const int cnt = std::min(max_complex, n.n_f);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = drain(c))
+        return rc;
     if (out && cnt > 0) {
         if (n.leaf) {
             HIPCHK(c, hipMemcpy(out, c->arena + n.off_stream[par] + sizeof(float2) * (size_t)n.Hx, sizeof(float2) * (size_t)cnt,
@@ -1126,7 +1354,9 @@ int sdrx_get_prequant(sdrx_ctx *c, int id, float *out, int max, int *n_ret)
     if (!c->finalized || !c->opt_prequant || !n.leaf || !n.d.demod_usb)
         return fail(c, SDRX_ESTATE, "sdrx_get_prequant: set option keep_prequant=1 before finalize; USB leaves only");
     const int cnt = std::min(max, n.n_out);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = drain(c))
+        return rc;
     if (out && cnt > 0)
         HIPCHK(c, hipMemcpy(out, c->arena + n.off_preq, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost));
     if (n_ret)
@@ -1147,6 +1377,7 @@ int sdrx_get_taps(sdrx_ctx *c, int id, int which, float *out, int max, int *n_re
     // read back what the kernels actually use (device copy), not the host vector
     const size_t off = which == 0 ? n.off_lpf + 3 * sizeof(float) : which == 1 ? n.off_dec : n.off_hilbert;
     const int cnt = std::min(max, (int)t->size());
+    HIPCHK(c, hipSetDevice(c->device));
     if (out && cnt > 0)
         HIPCHK(c, hipMemcpy(out, c->arena + off, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost));
     if (n_ret)
@@ -1165,6 +1396,7 @@ int sdrx_get_nco(sdrx_ctx *c, int id, long first, long count, float *out)
         return fail(c, SDRX_EINVAL, "table range [%ld,%ld) outside 0..%d", first, first + count, n.d.fs);
     if (count == 0)
         return SDRX_OK;
+    HIPCHK(c, hipSetDevice(c->device));
     float2 *tmp = nullptr;
     HIPCHK(c, hipMalloc(&tmp, sizeof(float2) * (size_t)count));
     hipLaunchKernelGGL(k_nco_dump, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream,
@@ -1190,8 +1422,9 @@ int sdrx_get_stats(sdrx_ctx *c, sdrx_stats *s)
     s->exact = c->opt_exact;
     s->algorithmic_bytes_per_frame = c->alg_bytes;
     s->vfo_samples_per_frame = c->vfo_samples;
-    s->device_bytes = (int64_t)(c->arena_bytes + c->pay_bytes + c->raw_cap * 10);
+    s->device_bytes = (int64_t)(c->arena_bytes + 2 * c->pay_bytes + c->raw_cap * 10);
     s->frames = (int64_t)c->frame_no;
+    s->mix_chunks_per_frame = c->mix_chunks;
     return SDRX_OK;
 }
 
@@ -1199,8 +1432,9 @@ int sdrx_enable_kernel_timing(sdrx_ctx *c, int enable)
 {
     if (!c)
         return SDRX_EINVAL;
-    (void)hipStreamSynchronize(c->stream);
-    drain_events(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = drain(c))
+        return rc;
     c->timing = enable != 0;
     for (int k = 0; k < SDRX_NKERNELS; ++k) {
         c->t_ms[k] = 0;
@@ -1215,8 +1449,9 @@ int sdrx_get_kernel_times(sdrx_ctx *c, double ms[SDRX_NKERNELS], int64_t launche
 {
     if (!c)
         return SDRX_EINVAL;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    drain_events(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = drain(c))
+        return rc;
     for (int k = 0; k < SDRX_NKERNELS; ++k) {
         if (ms)
             ms[k] = c->t_ms[k];

@@ -64,18 +64,19 @@ struct K2Vfo {
     float2 *s_next[2];
     const float *hnz;       // the 62 non-zero Hilbert taps hp[1], hp[3], ..., hp[123]
     const float *lpf_pad;   // audio low-pass taps with 3 zeros in front and >= 8 behind, or null
-    short *pay;             // n int16
+    short *pay[2];          // n int16, per frame parity (frame f's payload is copied out while f+1 is computed)
     float *prequant;        // optional n floats
     float gain;
     int H, n, nlpf;
     int tile;               // outputs per block: 1024, or 1024 - E with the low-pass (E = nlpf rounded up to even)
     int pad_;
 };
+static_assert(sizeof(K2Vfo) % 8 == 0, "K2Vfo array stride");
 
 // ---- compress() for childless non-USB VFOs (vfo.cpp:389-424) ----------------------------------
 struct K3Vfo {
     const float2 *s[2];
-    signed char *pay;
+    signed char *pay[2];    // per frame parity
     int n, cstyle, scalecomp;
     int pad_;
 };

@@ -38,21 +38,29 @@ def init_process_group(backend: str | None = None, device: torch.device | None =
 
 
 class FrameBroadcast:
-    """Double-buffered broadcast of the raw frame (2*n_complex float32) from `src_rank`.
+    """Double-buffered broadcast of raw frames from `src_rank`: `frames_per_batch` frames (each
+    2*n_complex float32) travel in ONE collective, so its launch and the stream synchronisation
+    around it are paid once per batch, not once per frame (4 frames = 1 s of signal = 12.3 MB at
+    1.536 MS/s; the latency a real receiver pays for batching is the ingest's, not the GPUs').
 
     Two ways to use it:
-      * ``buf = bc(frame)``: broadcast now, on the current stream (simple, serial);
-      * ``bc.submit(frame)`` ... ``buf = bc.result()`` ... ``bc.consumed()``: the broadcast of the
-        NEXT frame runs on a communication stream of its own while the current frame is being
-        processed.  ``result()`` makes the current (compute) stream wait for the pending broadcast,
-        ``consumed()`` marks, in compute-stream order, the point after which the buffer returned by
-        the previous ``result()`` may be overwritten."""
+      * ``buf = bc(frames)``: broadcast now, on the current stream (simple, serial);
+      * ``bc.submit(frames)`` ... ``buf = bc.result()``: the broadcast of the NEXT batch runs on a
+        communication stream of its own while the current batch is processed.  ``result()`` makes
+        the current (compute) stream wait for the pending broadcast.  ``submit()`` records ONE event
+        on the current stream that (a) orders the communication stream behind whatever produced
+        `frames` and (b) marks the buffer handed out by the previous ``result()`` as consumed --
+        so call it AFTER the work that reads that buffer has been enqueued on the current stream
+        (the Receiver must run on that stream: ``Receiver.set_stream``).  ``consumed()`` does (b)
+        alone for callers that want to release a buffer earlier."""
 
-    def __init__(self, n_complex: int, device: torch.device, src_rank: int = 0):
+    def __init__(self, n_complex: int, device: torch.device, src_rank: int = 0, frames_per_batch: int = 1):
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.src = src_rank
-        self.buf = [torch.empty(2 * n_complex, dtype=torch.float32, device=device) for _ in range(2)]
+        self.frames_per_batch = int(frames_per_batch)
+        self.frame_floats = 2 * n_complex
+        self.buf = [torch.empty(self.frames_per_batch * 2 * n_complex, dtype=torch.float32, device=device) for _ in range(2)]
         self.k = 0
         self.cuda = device.type == "cuda"
         self.comm = torch.cuda.Stream(device) if (self.cuda and self.world > 1) else None
@@ -60,8 +68,12 @@ class FrameBroadcast:
         self._free = [None, None]       # per buffer: event after which it may be overwritten
         self._last = None               # index of the buffer handed out by the last result()
 
+    def frame(self, batch: torch.Tensor, j: int) -> torch.Tensor:
+        """Frame j of a batch returned by result() / __call__."""
+        return batch[j * self.frame_floats:(j + 1) * self.frame_floats]
+
     def __call__(self, frame: torch.Tensor | None) -> torch.Tensor:
-        """`frame`: the new raw frame on the source rank (ignored elsewhere).  Returns this
+        """`frame`: the new batch on the source rank (ignored elsewhere).  Returns this
         rank's copy, valid until the call after next."""
         if self.world == 1:
             return frame
@@ -85,9 +97,17 @@ class FrameBroadcast:
                 b.copy_(frame)
             self._pending = (b, dist.broadcast(b, src=self.src, async_op=True), i)
             return
+        # one event on the caller's stream: everything enqueued so far -- the producer of `frame`
+        # and the consumer of the previously returned buffer -- is ahead of it
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        if self._last is not None:
+            self._free[self._last] = ev
         with torch.cuda.stream(self.comm):
-            if self._free[i] is not None:
-                self.comm.wait_event(self._free[i])  # the frame that last used this buffer has been consumed
+            if self.rank == self.src:
+                self.comm.wait_event(ev)
+            if self._free[i] is not None and self._free[i] is not ev:
+                self.comm.wait_event(self._free[i])  # the batch that last used this buffer has been consumed
             if self.rank == self.src:
                 b.copy_(frame, non_blocking=True)
             work = dist.broadcast(b, src=self.src, async_op=True)
@@ -106,6 +126,8 @@ class FrameBroadcast:
         return b
 
     def consumed(self) -> None:
+        """Marks, in the current stream's order, the point after which the buffer returned by the last
+        result() may be overwritten (submit() does the same)."""
         if self.world == 1 or not self.cuda or self._last is None:
             return
         ev = torch.cuda.Event()
@@ -121,14 +143,16 @@ class ShardedReceiver:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.full = topo
         self.topo = shard(topo, self.rank, self.world)
-        self.engine = make_engine(self.topo)
+        # more ranks than sub VFOs: this rank holds nothing and only takes part in the broadcast
+        self.engine = make_engine(self.topo) if self.topo.vfos else None
         self.device = device or torch.device("cpu")
         self.bcast = FrameBroadcast(topo.frame, self.device, src_rank)
 
     def process(self, frame: torch.Tensor | None):
         """One frame: broadcast the raw IQ, run the local shard.  Returns the local frame tensor."""
         local = self.bcast(frame)
-        self.engine.process(local)
+        if self.engine is not None:
+            self.engine.process(local)
         return local
 
     def leaf_topics(self) -> list[str]:

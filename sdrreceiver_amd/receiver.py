@@ -30,7 +30,7 @@ class Receiver:
     """One libsdrx context: a VFO tree on one GPU."""
 
     def __init__(self, device: int = 0, exact: bool = True, keep_prequant: bool = False, segments: int = 0,
-                 dc_blocked_scan: bool = False):
+                 dc_blocked_scan: bool = False, pipeline: bool = True):
         self.L = _lib.lib()
         h = C.c_void_p()
         rc = self.L.sdrx_create(C.byref(h), int(device))
@@ -45,6 +45,7 @@ class Receiver:
         self._chk(self.L.sdrx_set_option(self.h, b"keep_prequant", int(bool(keep_prequant))))
         self._chk(self.L.sdrx_set_option(self.h, b"segments", int(segments)))
         self._chk(self.L.sdrx_set_option(self.h, b"dc_blocked_scan", int(bool(dc_blocked_scan))))
+        self._chk(self.L.sdrx_set_option(self.h, b"pipeline", int(bool(pipeline))))
         self.finalized = False
 
     # -- plumbing -----------------------------------------------------------------
@@ -106,11 +107,33 @@ class Receiver:
         self._chk(self.L.sdrx_process_u8(self.h, b.ctypes.data, b.size // 2, int(bool(correct_dc))))
 
     def process_device(self, dev_ptr: int, n_complex: int) -> None:
+        self.published.clear()  # the payloads of this frame arrive with the next (explicit or implicit) fetch
         self._chk(self.L.sdrx_process_device(self.h, C.c_void_p(dev_ptr), int(n_complex)))
 
     def fetch(self) -> None:
         self.published.clear()
         self._chk(self.L.sdrx_fetch(self.h))
+
+    # -- pipelined interface: submit returns at once, wait delivers the oldest undelivered frame ------
+    def submit(self, iq) -> None:
+        iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
+        self._chk(self.L.sdrx_submit(self.h, iq.ctypes.data, iq.size // 2))
+
+    def submit_u8(self, iq_bytes, correct_dc: bool = False) -> None:
+        b = np.ascontiguousarray(iq_bytes, dtype=np.uint8).reshape(-1)
+        self._chk(self.L.sdrx_submit_u8(self.h, b.ctypes.data, b.size // 2, int(bool(correct_dc))))
+
+    def submit_device(self, dev_ptr: int, n_complex: int) -> None:
+        self._chk(self.L.sdrx_submit_device(self.h, C.c_void_p(dev_ptr), int(n_complex)))
+
+    def wait(self) -> None:
+        """Blocks until the oldest undelivered frame's payloads are on the host; `published` then
+        holds that frame's messages and output() serves it."""
+        self.published.clear()
+        self._chk(self.L.sdrx_wait(self.h))
+
+    def in_flight(self) -> int:
+        return int(self.L.sdrx_in_flight(self.h))
 
     def sync(self) -> None:
         self._chk(self.L.sdrx_sync(self.h))

@@ -85,11 +85,27 @@ class Topology:
     vfos: list[VfoDesc] = field(default_factory=list)
     name: str = ""
 
+    def _child_map(self) -> dict[int, list[int]]:
+        """parent index -> child indices in creation order, rebuilt when the node list changed
+        (one pass instead of one per query: config 5 has 65 538 nodes)."""
+        key = (id(self.vfos), len(self.vfos))  # nodes are appended, never re-parented in place
+        cached = self.__dict__.get("_cm")
+        if cached is None or cached[0] != key:
+            m: dict[int, list[int]] = {}
+            for i, v in enumerate(self.vfos):
+                m.setdefault(max(v.parent, -1), []).append(i)
+            cached = (key, m)
+            self.__dict__["_cm"] = cached
+        return cached[1]
+
     def children(self, idx: int) -> list[int]:
-        return [i for i, v in enumerate(self.vfos) if v.parent == idx]
+        return list(self._child_map().get(idx, ()))
 
     def roots(self) -> list[int]:
         return [i for i, v in enumerate(self.vfos) if v.parent < 0]
+
+    def is_leaf(self, idx: int) -> bool:
+        return idx not in self._child_map()
 
     def leaves_in_publish_order(self) -> list[int]:
         out: list[int] = []
@@ -384,19 +400,36 @@ def config5(n_subs: int = 65536) -> Topology:
 
 
 def shard(topo: Topology, rank: int, world: int) -> Topology:
-    """Static block partition of the sub VFOs of every main across `world` GPUs; the mains
-    (and parent-less leaves' raw stream) are replicated.  Node order, hence
-    publish order within the shard, is preserved."""
+    """Static block partition of the sub VFOs of every main across `world` GPUs; a main is
+    replicated on every rank that holds at least one of its subs.  The unit that
+    moves is a SUBTREE: a sub VFO goes to its rank with everything below it.  A main whose block
+    on this rank is empty (fewer subs than ranks) is NOT kept -- alone it would look like a
+    childless main, i.e. a compress() leaf that publishes IQ, which the reference never does for
+    a main that has subs (vfo.cpp:253-266).  Parent-less leaves are block-partitioned among
+    themselves.  Node order, hence publish order within the shard, is preserved; a rank can end
+    up with no VFOs at all (`len(shard.vfos) == 0`): it then only takes part in the broadcast."""
     if world <= 1:
         return topo
+    cm = topo._child_map()
     keep: list[int] = []
-    for r in topo.roots():
-        ch = topo.children(r)
+
+    def subtree(i):
+        stack = [i]
+        while stack:
+            j = stack.pop()
+            keep.append(j)
+            stack.extend(cm.get(j, ()))
+
+    roots = cm.get(-1, [])
+    for r in roots:
+        ch = cm.get(r, [])
         if ch:
-            keep.append(r)
             lo, hi = (len(ch) * rank) // world, (len(ch) * (rank + 1)) // world
-            keep.extend(ch[lo:hi])
-    flat = [r for r in topo.roots() if not topo.children(r)]
+            if hi > lo:
+                keep.append(r)
+                for c in ch[lo:hi]:
+                    subtree(c)
+    flat = [r for r in roots if not cm.get(r)]
     lo, hi = (len(flat) * rank) // world, (len(flat) * (rank + 1)) // world
     keep.extend(flat[lo:hi])
     keep.sort()

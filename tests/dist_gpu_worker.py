@@ -30,7 +30,11 @@ class Engine:
 def main():
     rank, world = D.init_process_group("gloo")
     dev = torch.device("cuda", 0)
-    full = tp.profile_25e()
+    # SDRX_DIST_TREE=config5-<n>: BASELINE config 5's tree shape (config-3 rule, n sub VFOs in total,
+    # sharded over the ranks); default: the sdr_25E profile
+    tree = os.environ.get("SDRX_DIST_TREE", "25e")
+    full = tp.config5(int(tree.split("-")[1])) if tree.startswith("config5-") else tp.profile_25e()
+    threads = max(1, len(os.sched_getaffinity(0)) // world)
     sr = D.ShardedReceiver(full, Engine, device=dev)
     nodes, roots = ob.build_tree("port", sr.topo)
     lcg = synth.Lcg(1)
@@ -38,7 +42,7 @@ def main():
         iq = synth.lcg_frame(full.frame, lcg)  # every rank can regenerate the frame for its checker ...
         src = torch.from_numpy(iq).to(dev) if rank == 0 else None  # ... but only rank 0 feeds the GPUs
         sr.process(src)
-        ob.process_roots(roots, iq)
+        ob.process_roots(roots, iq, threads=threads)
         rx = sr.engine.rx
         for i in sr.topo.leaves_in_publish_order():
             assert np.array_equal(rx.output(i), nodes[i].usb()), (rank, f, sr.topo.vfos[i].topic)
@@ -54,7 +58,7 @@ def main():
         bc.consumed()
         if f + 1 < 6:
             bc.submit(dev[f + 1])
-        ob.process_roots(roots, frames[f])
+        ob.process_roots(roots, frames[f], threads=threads)
         for i in sr.topo.leaves_in_publish_order():
             assert np.array_equal(sr.engine.rx.output(i), nodes[i].usb()), (rank, "overlap", f, sr.topo.vfos[i].topic)
     topics = sr.leaf_topics()

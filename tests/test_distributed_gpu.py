@@ -11,13 +11,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch():
+def _launch(tree="25e"):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SDRX_DIST_TREE=tree)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -42,3 +43,17 @@ def test_two_ranks_share_one_gpu():
         ok, outs = _launch()
     assert ok, "\n".join(outs)
     assert "OK 27 leaves over 2 ranks" in outs[0], outs[0]
+
+
+@pytest.mark.gpu
+def test_two_ranks_config5_shaped_tree():
+    """BASELINE config 5's tree shape (config-3 rule under the two sdr_25E mains) with 2 048 sub VFOs,
+    sharded over two ranks by distributed.ShardedReceiver exactly as `bench.py --gpus N` shards the
+    65 536-sub tree; every leaf of every shard bit-identical to the oracle, serial and overlapped
+    broadcast, and the union of the shards = the whole tree."""
+    ok, outs = _launch("config5-2048")
+    if not ok:
+        print("first attempt failed:\n" + "\n".join(outs))
+        ok, outs = _launch("config5-2048")
+    assert ok, "\n".join(outs)
+    assert "OK 2048 leaves over 2 ranks: [1024, 1024]" in outs[0], outs[0]

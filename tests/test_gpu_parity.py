@@ -168,8 +168,9 @@ def test_time_segmentation_is_invisible(Receiver):
                 assert np.array_equal(bits(a), bits(b))
 
 
+@pytest.mark.parametrize("pipeline", [True, False])
 @pytest.mark.parametrize("key", ["profile_25e", "54w"])
-def test_async_frames_back_to_back(Receiver, key):
+def test_async_frames_back_to_back(Receiver, key, pipeline):
     """sdrx_process_device is asynchronous: 9 frames queued on a caller's stream without any
     synchronisation in between (level 0 of a frame may start while the previous frame's
     demodulation is still running), one sdrx_fetch at the end.  Streams and payloads equal the
@@ -181,7 +182,7 @@ def test_async_frames_back_to_back(Receiver, key):
     for iq in frames:
         ob.process_roots(roots, iq)
     st = torch.cuda.Stream()
-    rx = Receiver.from_topology(topo, exact=True)
+    rx = Receiver.from_topology(topo, exact=True, pipeline=pipeline)
     rx.set_stream(st.cuda_stream)
     with torch.cuda.stream(st):
         dev = [torch.from_numpy(iq).cuda(non_blocking=True) for iq in frames]
@@ -189,6 +190,86 @@ def test_async_frames_back_to_back(Receiver, key):
             rx.process_device(d.data_ptr(), topo.frame)
     rx.fetch()
     _check_exact(rx, nodes, topo, ("async", key))
+    rx.close()
+
+
+@pytest.mark.parametrize("pipeline", [True, False])
+def test_submit_wait_delivers_frames_in_order(Receiver, pipeline):
+    """The pipelined interface (SURVEY 8b "async submit/wait pair"): submit(f+1); wait() -> f.  Every
+    delivered frame carries exactly the messages ZmqPublisher::publish would get for THAT frame
+    (topic, rate, payload; main order x sub order, vfo.cpp:426-453) while the next frame is already
+    queued behind it; the input buffer is borrowed for the duration of the call only; the in-flight
+    limit and the exclusion of the synchronous calls are enforced; afterwards the synchronous
+    interface continues the same stream of frames."""
+    from sdrreceiver_amd.receiver import SdrxError
+    topo = golden_topology("profile_25e")
+    rx = Receiver.from_topology(topo, pipeline=pipeline)
+    nodes, roots = ob.build_tree("port", topo)
+    order = topo.leaves_in_publish_order()
+    frames = [iq for _, iq in _frames(topo, 9, seed=3, tones=[(-377000.0, 25.0)])]
+    want = []
+    for iq in frames:
+        ob.process_roots(roots, iq)
+        want.append([(topo.vfos[i].topic.encode()[:5].ljust(5, b"\0"), topo.vfos[i].output_rate, nodes[i].usb().tobytes()) for i in order])
+    scratch = np.empty_like(frames[0])
+
+    def submit(f):
+        scratch[:] = frames[f]
+        rx.submit(scratch)
+        scratch[:] = -77.0  # the caller's buffer is free again as soon as the call returns
+
+    submit(0)
+    assert rx.in_flight() == 1
+    for f in range(1, 7):
+        submit(f)
+        assert rx.in_flight() == 2
+        if f == 1:
+            for call in (lambda: rx.submit(frames[f]), lambda: rx.process(frames[f]), rx.fetch, lambda: rx.output(order[0])):
+                with pytest.raises(SdrxError) as e:
+                    call()
+                assert e.value.code == -2
+        rx.wait()
+        assert rx.published == want[f - 1], (pipeline, f - 1)
+        assert rx.in_flight() == 1
+    rx.wait()
+    assert rx.published == want[6] and rx.in_flight() == 0
+    assert rx.output(order[-1]).tobytes() == want[6][-1][2]  # get_output serves the delivered frame
+    with pytest.raises(SdrxError) as e:
+        rx.wait()
+    assert e.value.code == -2
+    rx.process(frames[7])
+    assert rx.published == want[7]
+    rx.submit(frames[8])
+    rx.wait()
+    assert rx.published == want[8]
+    rx.close()
+
+
+def test_submit_u8_with_dc_correction(Receiver):
+    """sdrx_submit_u8: dongle bytes through the pipelined interface, DC-bias IIR on the device with its
+    state carried from frame to frame while two frames are in flight."""
+    topo = tp.config2()
+    rx = Receiver.from_topology(topo)
+    nodes, roots = ob.build_tree("port", topo)
+    order = topo.leaves_in_publish_order()
+    rng = np.random.default_rng(9)
+    state = np.zeros(2, np.float32)
+    frames, want = [], []
+    for f in range(4):
+        b = rng.integers(0, 256, 2 * topo.frame, dtype=np.uint8)
+        b[1::2] = np.clip(b[1::2].astype(int) // 8 + 120, 0, 255)
+        iq = ob.u8_to_float(b)
+        ob.dc_correct(iq, state)
+        ob.process_roots(roots, iq)
+        frames.append(b)
+        want.append([nodes[i].usb().tobytes() for i in order])
+    rx.submit_u8(frames[0], correct_dc=True)
+    for f in range(1, 4):
+        rx.submit_u8(frames[f], correct_dc=True)
+        rx.wait()
+        assert [p for _, _, p in rx.published] == want[f - 1], f - 1
+    rx.wait()
+    assert [p for _, _, p in rx.published] == want[3]
     rx.close()
 
 
@@ -230,26 +311,24 @@ def test_vfos_are_independent_and_shardable(Receiver):
 
 
 def test_full_size_properties_config3(Receiver):
-    """BASELINE config 3 at full size (1 024 sub VFOs): the oracle is too slow to check every
-    VFO every frame inside the GPU suite budget, so (a) a sample of VFOs is checked bit for bit
-    and (b) two size-independent properties hold for ALL of them: an all-zero frame after
-    start-up yields all-zero audio (zero state, linear chain), and VFOs with identical
-    parameters produce identical output."""
+    """BASELINE config 3 at full size (2 mains + 1 024 sub VFOs): EVERY VFO -- final complex stream
+    and int16 payload -- bit for bit against the oracle for 3 frames (the oracle runs its sub VFOs
+    on all host cores: ~0.1-0.5 s per frame), plus two size-independent properties: VFOs with
+    identical parameters produce identical output, and an all-zero frame after start-up yields
+    all-zero audio (zero state, linear chain)."""
+    import os
     topo = tp.config3(1024)
     topo.vfos.append(tp.VfoDesc(**{**topo.vfos[5].__dict__, "topic": "DUP05"}))  # duplicate of a main0 sub
     rx = Receiver.from_topology(topo)
-    lcg = synth.Lcg(1)
-    iq = synth.lcg_frame(topo.frame, lcg)
-    sample = [2, 3, 200, 513, 514, 515, 900, 1025]
-    sub = tp.Topology(fs=topo.fs, frame=topo.frame, vfos=[topo.vfos[0], topo.vfos[1]] + [topo.vfos[i] for i in sample])
-    nodes, roots = ob.build_tree("port", sub)
-    for f in range(2):
+    nodes, roots = ob.build_tree("port", topo)
+    threads = len(os.sched_getaffinity(0))
+    for f, iq in _frames(topo, 3, seed=1):
         rx.process(iq)
-        ob.process_roots(roots, iq)
-        for k, i in enumerate(sample):
-            assert np.array_equal(rx.output(i), nodes[2 + k].usb()), (f, i)
+        ob.process_roots(roots, iq, threads=threads)
+        _check_exact(rx, nodes, topo, ("config3-full", f))
         assert np.array_equal(rx.output(5), rx.output(len(topo.vfos) - 1))
-        iq = synth.lcg_frame(topo.frame, lcg)
+    for r in roots:
+        r.free()
     rx.close()
     rx = Receiver.from_topology(topo)
     rx.process(np.zeros(2 * topo.frame, np.float32))

@@ -135,6 +135,46 @@ def test_shard_is_a_partition():
     assert sorted(seen) == sorted(v.topic for v in t.vfos if v.parent >= 0)
 
 
+def test_shard_never_turns_a_main_into_a_leaf():
+    """More ranks than a main has subs: a main whose block on a rank is empty must not stay behind
+    as a childless (compress / IQ-publishing) leaf -- the reference never publishes IQ for a main
+    that has subs (vfo.cpp:253-266) -- and a rank may end up empty."""
+    t = tp.profile_25e()  # 12 + 15 subs
+    for world in (16, 32):
+        topics = []
+        for r in range(world):
+            s = tp.shard(t, r, world)
+            leaves = s.leaves_in_publish_order()
+            assert all(s.vfos[i].demod_usb for i in leaves), (world, r)
+            assert all(v.parent < 0 or s.vfos[v.parent].parent < 0 for v in s.vfos)
+            topics += [s.vfos[i].topic for i in leaves]
+        assert sorted(topics) == sorted(v.topic for v in t.vfos if v.parent >= 0)
+    c1 = tp.config1()  # one main, one sub: rank 0 of 2 has nothing, rank 1 the whole chain
+    assert [len(tp.shard(c1, r, 2).vfos) for r in range(2)] == [0, 2]
+
+
+def test_shard_moves_whole_subtrees():
+    """A three-level tree: the unit that moves is a sub VFO with everything below it."""
+    t = tp.Topology(fs=1536000, frame=384000)
+    t.vfos.append(tp.VfoDesc(parent=-1, fs=1536000, decimate_count=2, mixer_freq=484000.0, demod_usb=False, cstyle=1,
+                             samples_per_buffer=384000))
+    for k in range(4):
+        mid = len(t.vfos)
+        t.vfos.append(tp.VfoDesc(parent=0, fs=384000, decimate_count=1, mixer_freq=1000.0 * k, demod_usb=False, cstyle=1,
+                                 samples_per_buffer=96000))
+        for j in range(3):
+            t.vfos.append(tp.VfoDesc(topic=f"L{k}{j}", parent=mid, fs=192000, decimate_count=2, mixer_freq=500.0 * j,
+                                     samples_per_buffer=48000))
+    seen = []
+    for r in range(2):
+        s = tp.shard(t, r, 2)
+        assert len(s.vfos) == 1 + 2 * 4
+        leaves = s.leaves_in_publish_order()
+        assert all(s.vfos[i].demod_usb for i in leaves) and len(leaves) == 6
+        seen += [s.vfos[i].topic for i in leaves]
+    assert sorted(seen) == sorted(v.topic for v in t.vfos if v.topic)
+
+
 def test_lcg_vectorised_matches_scalar():
     x, ref = 1, []
     for _ in range(64):
