@@ -189,7 +189,9 @@ def main():
     ap.add_argument("--fast", action="store_true", help="FMA arithmetic (within 1e-6 of the reference) instead of bit-exact")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-abi", action="store_true", help="skip the through-the-ABI (host buffers, PCIe both ways) leg")
-    ap.add_argument("--no-pipeline", action="store_true", help="leaf tail on the same stream as the levels (A/B switch)")
+    ap.add_argument("--pipeline", action="store_true", help="leaf tail on a second stream beside the next frame's levels (A/B switch; slower)")
+    ap.add_argument("--no-fuse", action="store_true", help="one k_mix_decimate launch per tree level instead of k_mix_levels (A/B switch)")
+    ap.add_argument("--no-frame-pipeline", action="store_true", help="k_mix_levels, but every frame runs through all its levels at once (A/B switch)")
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0, help="frames per broadcast at N > 1 (default 4)")
     ap.add_argument("--configs1", action="store_true",
@@ -254,7 +256,8 @@ def main():
             self.topo = tp.shard(self.full, rank, world)
             self.frame = self.full.frame
             self.rx = Receiver.from_topology(self.topo, device=local, exact=not args.fast, segments=args.segments,
-                                             pipeline=not args.no_pipeline) if self.topo.vfos else None
+                                             pipeline=args.pipeline, fuse=not args.no_fuse,
+                                             frame_pipeline=not args.no_frame_pipeline) if self.topo.vfos else None
             if self.rx:
                 self.rx.set_stream(stream.cuda_stream)
             self.st = self.rx.stats() if self.rx else {"vfo_samples_per_frame": 0, "algorithmic_bytes_per_frame": 0, "n_leaves": 0,
@@ -429,7 +432,11 @@ def main():
             "config": {"workload": descr, "name": full.name, "vfos_total": int(len(full.vfos)), "sub_vfos_per_gpu": int(st["n_leaves"]),
                        "frame_cf32": full.frame, "fs": full.fs, "arithmetic": "fast-fma" if args.fast else "exact (bit-identical to -O2 reference)",
                        "parallelism": (f"vfo-shard x{world}, raw frames RCCL broadcast ({batch} per collective)" if world > 1 else "single GPU"),
-                       "frame_pipeline": "off" if args.no_pipeline else "leaf tail of frame f beside the levels of frame f+1 (2 HIP streams)"},
+                       "launches": ("separate kernels, leaf tail of frame f beside the levels of frame f+1 (2 HIP streams)" if args.pipeline
+                                    else "one kernel launch per tree level + leaf tail" if args.no_fuse
+                                    else "k_mix_levels, one level per launch + leaf tail" if args.no_frame_pipeline
+                                    else "per step ONE k_mix_levels launch (level l works on frame k-l: software pipeline over the frames "
+                                         "queued back to back) + the leaf tail of the frame that left the last level")},
             "repetitions": len(reps), "ms_per_step_min": round(min(reps) / args.steps * 1e3, 4),
             "ms_per_step_max": round(max(reps) / args.steps * 1e3, 4),
             "timed_region_ms_total": round(sum(reps) * 1e3, 1),

@@ -3,7 +3,7 @@
 // frames to sdrj::demodData, receive every leaf's payload through the publish hook.
 //
 //   sdrx_demo <profile.ini> --dump              descriptors as JSON lines (no GPU needed)
-//   sdrx_demo <profile.ini> --frames N [--u8] [--fft TOPIC]
+//   sdrx_demo <profile.ini> --frames N [--u8] [--fft TOPIC] [--devices 0,1,...]
 //                                               N synthetic LCG frames; one line per published
 //                                               message: frame topic rate bytes fnv1a64(payload)
 #include <cinttypes>
@@ -58,13 +58,22 @@ int main(int argc, char **argv)
         const int frames = std::atoi(argv[3]);
         bool u8 = false;
         std::string fft_topic;
+        std::vector<int> devices;
         for (int a = 4; a < argc; ++a) {
             if (std::string(argv[a]) == "--u8")
                 u8 = true;
             else if (std::string(argv[a]) == "--fft" && a + 1 < argc)
                 fft_topic = argv[++a];
+            else if (std::string(argv[a]) == "--devices" && a + 1 < argc) { // one tree sharded over several GPUs
+                std::stringstream ss(argv[++a]);
+                std::string tok;
+                while (std::getline(ss, tok, ','))
+                    devices.push_back(std::atoi(tok.c_str()));
+            }
         }
-        sdrj radio(0);
+        if (devices.empty())
+            devices.push_back(0);
+        sdrj radio(devices);
         radio.setVFOs(&P->mains);
         radio.setDCCorrection(P->correct_dc);
         int frame_no = 0;

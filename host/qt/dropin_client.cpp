@@ -13,6 +13,7 @@
 #include <QVector>
 #include <cstdint>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -50,9 +51,16 @@ extern "C" {
 // fft_topic (may be empty) is handed to every vfo's fftVFOSlot; each fftData emission is logged
 // to fft_out as "frame topic count fnv1a64\n".  Returns the number of bytes written to out, or
 // < 0 on error.
+// `copies` > 1 builds that many independent receivers from the same description (MainWindow builds
+// one; nothing in vfo.h forbids more) and feeds every frame to each in turn: the subscriber then sees
+// the same messages `copies` times per frame.
 int dropin_run(const sdrx_vfo_desc *descs, int n, const char *addr, int frames, const char *fft_topic, unsigned char *out, int cap,
-               char *fft_out, int fft_cap)
+               char *fft_out, int fft_cap, int copies)
 {
+    if (copies < 1)
+        copies = 1;
+    const int n1 = n;
+    n *= copies;
     std::vector<vfo *> nodes((size_t)n);
     std::vector<QVector<vfo *> *> kids((size_t)n, nullptr);
     QVector<vfo *> mains;
@@ -60,7 +68,9 @@ int dropin_run(const sdrx_vfo_desc *descs, int n, const char *addr, int frames, 
     int frame_no = 0;
     int root_frame = 0;
     for (int i = 0; i < n; ++i) {
-        const sdrx_vfo_desc &d = descs[i];
+        sdrx_vfo_desc d = descs[i % n1];
+        if (d.parent_id >= 0)
+            d.parent_id += (i / n1) * n1;
         vfo *v = new vfo();
         v->setZmqAddress(QString::fromUtf8(addr));
         v->setZmqTopic(QString::fromLatin1(d.topic));
@@ -169,6 +179,38 @@ int dropin_run(const sdrx_vfo_desc *descs, int n, const char *addr, int frames, 
         fft_out[k] = 0;
     }
     return (int)all.size();
+}
+
+// Does vfo::init throw for this description, and what?  Returns 1 and the exception's what() text where
+// the reference's firfilter::sanity_check_1f throws std::out_of_range (vfo.cpp:82-87,110-115), 0 where
+// init returns normally, 2 for any other exception.
+int dropin_init_probe(const sdrx_vfo_desc *d, const char *addr, char *what, int cap)
+{
+    vfo *v = new vfo();
+    v->setZmqAddress(QString::fromUtf8(addr));
+    v->setZmqTopic(QString::fromLatin1(d->topic));
+    v->setFs(d->fs);
+    v->setDecimationCount(d->decimate_count);
+    v->setMixerFreq(d->mixer_freq_hz);
+    v->setDemodUSB(d->demod_usb != 0);
+    v->setFilterBandwidth(d->filter_bw_hz);
+    v->setGain(d->gain);
+    int rc = 0;
+    try {
+        v->init(d->samples_per_buffer, true, d->late_decimate);
+    } catch (const std::out_of_range &e) {
+        rc = 1;
+        if (what && cap > 0) {
+            std::strncpy(what, e.what(), (size_t)cap - 1);
+            what[cap - 1] = 0;
+        }
+    } catch (...) {
+        rc = 2;
+    }
+    // (an object whose init threw is not deleted: the reference's destructor would free members init never set)
+    if (rc == 0)
+        delete v;
+    return rc;
 }
 
 } // extern "C"

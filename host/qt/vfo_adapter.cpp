@@ -1,26 +1,37 @@
 // host/qt/vfo_adapter.cpp -- `class vfo` of the reference's UNMODIFIED vfo.h, implemented over
 // libsdrx.so.  This is the file a maintainer puts in place of vfo.cpp:
-// mainwindow.cpp, sdrj.cpp and zmqpublisher.cpp stay as they are; oscillator.cpp,
-// halfbanddecimator.cpp, jonti/dsp.cpp and gnuradio/firfilter.cpp are no longer linked (only
-// their headers are still included by vfo.h for the now unused private members).
+// zmqpublisher.cpp stays as it is and is still linked; oscillator.cpp, halfbanddecimator.cpp,
+// jonti/dsp.cpp and gnuradio/firfilter.cpp are no longer linked (only their headers are still
+// included by vfo.h for the now unused private members).
 //
 // How the reference's per-object interface maps onto the whole-tree C ABI:
 //   * setters only record parameters in the object's own (private) members, as in vfo.cpp:177-233;
-//   * init() records the frame length, computes outputRate and does the ZMQ bind/connect exactly
-//     as vfo.cpp:160-172 does (the sockets stay on the host);
-//   * the first process() call commits the tree to the GPU: main VFOs are the initialised objects
-//     nobody holds in an mpVFOs list, in creation order (the order sdrj's list has,
-//     mainwindow.cpp:98-147), children in list order -- ids are creation order = publish order;
-//   * sdrj::demodData calls process() on every main VFO with the same frame (sdrj.cpp:288-294):
-//     the first main VFO submits the frame, the calls on the other mains return at once;
-//   * every leaf's payload comes back through the library's publish callback in the reference's
-//     order and goes out through transmitData() -> the unchanged ZmqPublisher::publish;
+//   * init() records the frame length, computes outputRate, does the ZMQ bind/connect exactly as
+//     vfo.cpp:160-172 does (the sockets stay on the host) and validates the filter specification on
+//     the host: where the reference's init throws std::out_of_range from firfilter::sanity_check_1f
+//     (vfo.cpp:82-87,110-115 -> firfilter.cpp:122-134) this init throws the same exception with the
+//     same what() text;
+//   * a TREE is keyed by its ROOT object: the first process() call on a vfo nobody holds in an mpVFOs
+//     list commits that vfo and everything below it (children in list order: ids are creation order
+//     = the reference's publish order, vfo.cpp:257-263) to a context of its own.  sdrj::demodData
+//     calls process() on every main VFO in turn (sdrj.cpp:288-294): each main runs its own subtree,
+//     exactly the reference's semantics, so any number of receivers can live in one process, and
+//     deleting a root (MainWindow's stop, vfo.cpp:34-59) frees its context -- the next start builds a
+//     new one;
+//   * every leaf's payload comes back through the library's publish callback in the reference's order
+//     and goes out through transmitData() -> the unchanged ZmqPublisher::publish;
 //   * fftData carries decimate[decimateCount] of the node fftVFOSlot selected (vfo.cpp:290-293).
+//
+// Device selection (environment, read when a tree is committed): SDRX_DEVICE=<ordinal> (default 0), or
+// SDRX_DEVICES=<a,b,...>: the tree sharded over several GPUs of the node (sdrx_group_*).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
 #include <unordered_map>
-#include <unordered_set>
 
 #include "vfo.h"
 
@@ -29,26 +40,54 @@
 ZmqPublisher vfo::bind_publisher; // vfo.h:66 (static, shared by all binding VFOs)
 
 namespace {
+
+// One committed tree = one receiver rooted at one main VFO.
+struct Tree {
+    sdrx_ctx *ctx = nullptr;   // one device ...
+    sdrx_group *grp = nullptr; // ... or several
+    std::vector<vfo *> nodes;  // by library id
+    std::vector<vfo *> leaves; // in publish order
+    size_t cursor = 0;         // next leaf the publish callback serves
+    ~Tree()
+    {
+        if (ctx)
+            sdrx_destroy(ctx);
+        if (grp)
+            sdrx_group_destroy(grp);
+    }
+    const char *error() const { return grp ? sdrx_group_last_error(grp) : sdrx_last_error(ctx); }
+};
+
+// What the adapter must remember per object and the unmodified header has no member for.
 struct NodeState {
     int id = -1;
     int samples_per_buffer = 0;
     int late_decimate = 0;
+    bool initialised = false;
+    std::shared_ptr<Tree> tree; // the tree this object was committed to (shared by all its nodes)
 };
-struct Registry {
-    sdrx_ctx *ctx = nullptr;
-    bool committed = false;
-    std::vector<vfo *> created;                       // initialised objects, in init() order
-    std::unordered_map<const vfo *, NodeState> state;
-    std::vector<vfo *> nodes;                         // by library id
-    std::vector<vfo *> leaves;                        // in publish order
-    size_t cursor = 0;                                // next leaf the publish callback serves
-    vfo *first_main = nullptr;
-} g;
 
-void fatal(const char *what)
+std::unordered_map<const vfo *, NodeState> &side()
 {
-    qFatal("sdrx adapter: %s: %s", what, sdrx_last_error(g.ctx));
+    static std::unordered_map<const vfo *, NodeState> s;
+    return s;
 }
+
+std::vector<int> devices_from_env()
+{
+    std::vector<int> d;
+    if (const char *e = std::getenv("SDRX_DEVICES")) {
+        std::stringstream ss(e);
+        std::string tok;
+        while (std::getline(ss, tok, ','))
+            if (!tok.empty())
+                d.push_back(std::atoi(tok.c_str()));
+    }
+    if (d.empty())
+        d.push_back(std::getenv("SDRX_DEVICE") ? std::atoi(std::getenv("SDRX_DEVICE")) : 0);
+    return d;
+}
+
 } // namespace
 
 vfo::vfo(QObject *parent) : QObject(parent)
@@ -80,12 +119,8 @@ vfo::~vfo()
     if (mpVFOs) // a vfo owns its children (vfo.cpp:49-57)
         for (int a = 0; a < mpVFOs->length(); ++a)
             delete mpVFOs->at(a);
-    g.state.erase(this);
-    g.created.erase(std::remove(g.created.begin(), g.created.end(), this), g.created.end());
-    if (g.created.empty() && g.ctx) { // the receiver was stopped: the next start builds a new tree
-        sdrx_destroy(g.ctx);
-        g = Registry();
-    }
+    // the tree (context, device memory) goes when its last node does: the root is deleted last
+    side().erase(this);
 }
 
 void vfo::setZmqAddress(QString address) { zmqAddress = address; }
@@ -116,13 +151,27 @@ void vfo::fftVFOSlot(QString topic) // vfo.cpp:492-509
 
 void vfo::init(int samplesPerBuffer, bool bind, int lateDecimate)
 {
-    if (g.committed)
-        qFatal("sdrx adapter: vfo::init after the first process() -- delete the VFOs and build the tree again");
-    NodeState &st = g.state[this];
+    NodeState &st = side()[this];
+    if (st.tree)
+        qFatal("sdrx adapter: vfo::init on a VFO whose tree is already running -- delete the tree and build it again");
     st.samples_per_buffer = samplesPerBuffer;
     st.late_decimate = (demodUSB && lateDecimate > 0) ? lateDecimate : 0; // vfo.cpp:69
-    if (std::find(g.created.begin(), g.created.end(), this) == g.created.end())
-        g.created.push_back(this);
+    // vfo::init designs its filters here and lets firfilter::sanity_check_1f throw (vfo.cpp:82-87,110-115)
+    {
+        sdrx_vfo_desc d;
+        std::memset(&d, 0, sizeof d);
+        d.fs = Fs;
+        d.decimate_count = decimateCount;
+        d.demod_usb = demodUSB ? 1 : 0;
+        d.late_decimate = st.late_decimate;
+        d.filter_bw_hz = filterbw;
+        d.samples_per_buffer = samplesPerBuffer;
+        d.parent_id = -1;
+        char why[160];
+        if (sdrx_check_vfo(&d, why, sizeof why) == SDRX_EFILTER)
+            throw std::out_of_range(why);
+    }
+    st.initialised = true;
     int targetRate = Fs / (pow(2, decimateCount)); // vfo.cpp:65,74,102
     if (st.late_decimate > 0)
         targetRate = targetRate / lateDecimate;
@@ -156,89 +205,101 @@ void vfo::compress() {}
 
 void vfo::process(const std::vector<cpx_typef> &samples)
 {
-    if (!g.committed) {
-        if (sdrx_create(&g.ctx, 0) != SDRX_OK)
-            qFatal("sdrx adapter: sdrx_create: %s", sdrx_last_error(nullptr));
-        std::unordered_set<const vfo *> children;
-        for (vfo *v : g.created)
-            if (v->mpVFOs)
-                for (vfo *c : *v->mpVFOs)
-                    children.insert(c);
+    NodeState &me = side()[this];
+    if (!me.tree) {
+        // first frame for this root: commit it and everything below it
+        std::shared_ptr<Tree> T = std::make_shared<Tree>();
+        const std::vector<int> devices = devices_from_env();
+        if (devices.size() > 1) {
+            if (sdrx_group_create(&T->grp, devices.data(), (int)devices.size()) != SDRX_OK)
+                qFatal("sdrx adapter: sdrx_group_create: %s", sdrx_group_last_error(nullptr));
+        } else if (sdrx_create(&T->ctx, devices[0]) != SDRX_OK) {
+            qFatal("sdrx adapter: sdrx_create(%d): %s", devices[0], sdrx_last_error(nullptr));
+        }
         struct Walk {
-            static void add(vfo *v, int parent)
+            static void add(Tree &T, const std::shared_ptr<Tree> &sp, vfo *v, int parent)
             {
-                auto it = g.state.find(v);
-                if (it == g.state.end())
+                NodeState &st = side()[v];
+                if (!st.initialised)
                     qFatal("sdrx adapter: a VFO of the tree was never initialised (vfo::init)");
+                if (st.tree)
+                    qFatal("sdrx adapter: a VFO is reachable from two roots");
                 sdrx_vfo_desc d;
                 std::memset(&d, 0, sizeof d);
                 d.fs = v->Fs;
                 d.decimate_count = v->decimateCount;
                 d.mixer_freq_hz = v->mixer_freq;
                 d.demod_usb = v->demodUSB ? 1 : 0;
-                d.late_decimate = it->second.late_decimate;
+                d.late_decimate = st.late_decimate;
                 d.filter_bw_hz = v->filterbw;
                 d.gain = v->gain;
                 d.cstyle = v->cstyle;
                 d.scalecomp = v->scalecomp;
                 d.parent_id = parent;
-                d.samples_per_buffer = it->second.samples_per_buffer;
+                d.samples_per_buffer = st.samples_per_buffer;
                 const QByteArray t = v->zmqTopic.toUtf8();
                 std::memcpy(d.topic, t.constData(), std::min<size_t>((size_t)t.size(), sizeof(d.topic) - 1));
-                if (sdrx_add_vfo(g.ctx, &d, &it->second.id) != SDRX_OK)
-                    fatal("sdrx_add_vfo");
-                g.nodes.push_back(v);
+                const int rc = T.grp ? sdrx_group_add_vfo(T.grp, &d, &st.id) : sdrx_add_vfo(T.ctx, &d, &st.id);
+                if (rc != SDRX_OK)
+                    qFatal("sdrx adapter: sdrx_add_vfo: %s", T.error());
+                st.tree = sp;
+                T.nodes.push_back(v);
                 const bool leaf = !v->mpVFOs || v->mpVFOs->isEmpty();
                 if (leaf)
-                    g.leaves.push_back(v);
+                    T.leaves.push_back(v);
                 else
                     for (vfo *c : *v->mpVFOs)
-                        add(c, it->second.id);
+                        add(T, sp, c, st.id);
             }
         };
-        for (vfo *v : g.created)
-            if (!children.count(v)) {
-                if (!g.first_main)
-                    g.first_main = v;
-                Walk::add(v, -1);
-            }
+        Walk::add(*T, T, this, -1);
         // a lambda inside a member function may touch private members: the payload lands in the
         // object's own transmit buffer and leaves through its own transmitData()
-        sdrx_set_publish_callback(
-            g.ctx,
-            [](void *, const char *, uint32_t, const void *buf, uint32_t len) {
-                // leaves that publish nothing (non-USB without a topic) are skipped by the library too
-                while (g.cursor < g.leaves.size() && !g.leaves[g.cursor]->demodUSB && g.leaves[g.cursor]->zmqTopic.length() == 0)
-                    ++g.cursor;
-                if (g.cursor >= g.leaves.size())
-                    return;
-                vfo *v = g.leaves[g.cursor++];
-                if (v->demodUSB)
-                    v->transmit_usb.assign((const short *)buf, (const short *)buf + len / sizeof(short));
-                else
-                    v->transmit_iq.assign((const signed char *)buf, (const signed char *)buf + len);
-                v->transmitData();
-            },
-            nullptr);
-        if (sdrx_finalize(g.ctx) != SDRX_OK) // the reference throws std::out_of_range from init here (firfilter.cpp:122-134)
-            fatal("sdrx_finalize");
-        g.committed = true;
+        sdrx_publish_fn deliver = [](void *user, const char *, uint32_t, const void *buf, uint32_t len) {
+            Tree &T = *static_cast<Tree *>(user);
+            // leaves that publish nothing (non-USB without a topic) are skipped by the library too
+            while (T.cursor < T.leaves.size() && !T.leaves[T.cursor]->demodUSB && T.leaves[T.cursor]->zmqTopic.length() == 0)
+                ++T.cursor;
+            if (T.cursor >= T.leaves.size())
+                return;
+            vfo *v = T.leaves[T.cursor++];
+            if (v->demodUSB)
+                v->transmit_usb.assign((const short *)buf, (const short *)buf + len / sizeof(short));
+            else
+                v->transmit_iq.assign((const signed char *)buf, (const signed char *)buf + len);
+            v->transmitData();
+        };
+        if (T->grp)
+            sdrx_group_set_publish_callback(T->grp, deliver, T.get());
+        else
+            sdrx_set_publish_callback(T->ctx, deliver, T.get());
+        // (filter specifications were validated in init(); what can still fail here is a geometry the
+        // kernels do not handle -- not an error path of the reference)
+        if ((T->grp ? sdrx_group_finalize(T->grp) : sdrx_finalize(T->ctx)) != SDRX_OK)
+            qFatal("sdrx adapter: sdrx_finalize: %s", T->error());
     }
-    if (this != g.first_main)
-        return; // the first main VFO's call processed the whole tree for this frame
-    g.cursor = 0;
-    if (sdrx_process(g.ctx, reinterpret_cast<const float *>(samples.data()), (int)samples.size()) != SDRX_OK)
-        fatal("sdrx_process");
-    for (vfo *v : g.nodes) // vfo.cpp:290-293
+    if (me.id != 0)
+        qFatal("sdrx adapter: vfo::process called on a VFO that is a child in a running tree");
+    Tree &T = *me.tree;
+    T.cursor = 0;
+    const float *iq = reinterpret_cast<const float *>(samples.data());
+    if ((T.grp ? sdrx_group_process(T.grp, iq, (int)samples.size()) : sdrx_process(T.ctx, iq, (int)samples.size())) != SDRX_OK)
+        qFatal("sdrx adapter: sdrx_process: %s", T.error());
+    for (vfo *v : T.nodes) // vfo.cpp:290-293
         if (v->emitFFT) {
-            int n = 0;
-            const int id = g.state[v].id;
-            if (sdrx_get_stream(g.ctx, id, nullptr, 0, &n) != SDRX_OK)
-                fatal("sdrx_get_stream");
+            int n = 0, id = side()[v].id;
+            sdrx_ctx *c = T.ctx;
+            if (T.grp) {
+                int member = -1;
+                if (sdrx_group_locate(T.grp, id, &member, &id) != SDRX_OK || sdrx_group_member(T.grp, member, &c, nullptr) != SDRX_OK || !c)
+                    qFatal("sdrx adapter: sdrx_group_locate: %s", T.error());
+            }
+            if (sdrx_get_stream(c, id, nullptr, 0, &n) != SDRX_OK)
+                qFatal("sdrx adapter: sdrx_get_stream: %s", sdrx_last_error(c));
             std::vector<cpx_typef> &dst = v->decimate[v->decimateCount];
             dst.resize((size_t)n);
-            if (sdrx_get_stream(g.ctx, id, reinterpret_cast<float *>(dst.data()), n, &n) != SDRX_OK)
-                fatal("sdrx_get_stream");
+            if (sdrx_get_stream(c, id, reinterpret_cast<float *>(dst.data()), n, &n) != SDRX_OK)
+                qFatal("sdrx adapter: sdrx_get_stream: %s", sdrx_last_error(c));
             emit v->fftData(dst);
         }
 }

@@ -81,11 +81,20 @@ using publish_fn = std::function<void(const char topic[5], uint32_t rate, const 
 
 class sdrj {
 public:
-    explicit sdrj(int device = 0) : device_(device) {}
+    explicit sdrj(int device = 0) : devices_(1, device) {}
+    // One tree on several GPUs of the node (sdrx_group_*): sub VFOs block-partitioned per main VFO, the raw
+    // frame fanned out from the first device over xGMI.  A device may be named twice (two shards on one GPU).
+    explicit sdrj(std::vector<int> devices) : devices_(std::move(devices))
+    {
+        if (devices_.empty())
+            devices_.push_back(0);
+    }
     ~sdrj()
     {
         if (ctx_)
             sdrx_destroy(ctx_);
+        if (grp_)
+            sdrx_group_destroy(grp_);
     }
     sdrj(const sdrj &) = delete;
     sdrj &operator=(const sdrj &) = delete;
@@ -108,7 +117,17 @@ public:
     {
         if (!mpVFOs || mpVFOs->empty())
             throw std::runtime_error("sdrj: no main VFOs");
-        check(sdrx_create(&ctx_, device_), "sdrx_create");
+        if (devices_.size() > 1) {
+            check(sdrx_group_create(&grp_, devices_.data(), (int)devices_.size()), "sdrx_group_create");
+            for (auto &kv : options_)
+                check(sdrx_group_set_option(grp_, kv.first.c_str(), kv.second), "sdrx_group_set_option");
+            for (vfo *m : *mpVFOs)
+                add(m, -1);
+            check(sdrx_group_set_publish_callback(grp_, &sdrj::trampoline, this), "sdrx_group_set_publish_callback");
+            check(sdrx_group_finalize(grp_), "sdrx_group_finalize");
+            return;
+        }
+        check(sdrx_create(&ctx_, devices_[0]), "sdrx_create");
         for (auto &kv : options_)
             check(sdrx_set_option(ctx_, kv.first.c_str(), kv.second), "sdrx_set_option");
         for (vfo *m : *mpVFOs)
@@ -120,53 +139,103 @@ public:
     // sdrj::demodData(const float*, int) (sdrj.cpp:266-305): `len` floats, interleaved I/Q.
     void demodData(const float *data, int len)
     {
-        if (!ctx_)
+        if (!started())
             start();
         const float *in = data;
-        if (correctDC) { // sdrj.cpp:271-286, on the host exactly where the reference has it
+        if (correctDC || (grp_ && emitFFT)) // (a group keeps the host's copy for the raw spectrum tap)
             samples_.assign(data, data + len);
-            const float keep = 1.0f - 0.000001f, k = 0.000001f;
-            for (int i = 0; i + 1 < len; i += 2) {
-                avept_[0] = avept_[0] * keep + k * samples_[(size_t)i];
-                avept_[1] = avept_[1] * keep + k * samples_[(size_t)i + 1];
-                samples_[(size_t)i] -= avept_[0];
-                samples_[(size_t)i + 1] -= avept_[1];
-            }
+        if (correctDC) { // sdrj.cpp:271-286, on the host exactly where the reference has it
+            dc_correct(samples_);
             in = samples_.data();
         }
-        check(sdrx_process(ctx_, in, len / 2), "sdrx_process");
+        if (grp_)
+            check(sdrx_group_process(grp_, in, len / 2), "sdrx_group_process");
+        else
+            check(sdrx_process(ctx_, in, len / 2), "sdrx_process");
         after_frame(len / 2);
     }
-    // rtl_tcp / dongle bytes (sdrj.cpp:149-165): LUT and DC correction on the device.
+    // rtl_tcp / dongle bytes (sdrj.cpp:149-165): LUT and DC correction on the device.  On several devices
+    // the bytes themselves are fanned out (a quarter of the traffic) unless the DC-bias IIR is on: that
+    // recurrence runs once, on the host as in the reference (sdrj.cpp:155-160,271-286), and floats travel.
     void demodBytes(const uint8_t *bytes, int n_complex)
     {
-        if (!ctx_)
+        if (!started())
             start();
-        check(sdrx_process_u8(ctx_, bytes, n_complex, correctDC ? 1 : 0), "sdrx_process_u8");
+        if (!grp_) {
+            check(sdrx_process_u8(ctx_, bytes, n_complex, correctDC ? 1 : 0), "sdrx_process_u8");
+        } else if (!correctDC) {
+            if (emitFFT) {
+                samples_.resize((size_t)2 * n_complex);
+                for (size_t i = 0; i < samples_.size(); ++i)
+                    samples_[i] = (float)((int)bytes[i] - 127);
+            }
+            check(sdrx_group_submit_u8(grp_, bytes, n_complex), "sdrx_group_submit_u8");
+            check(sdrx_group_wait(grp_), "sdrx_group_wait");
+        } else {
+            samples_.resize((size_t)2 * n_complex);
+            for (size_t i = 0; i < samples_.size(); ++i)
+                samples_[i] = (float)((int)bytes[i] - 127); // jonti/sdr.cpp:43-49
+            dc_correct(samples_);
+            check(sdrx_group_process(grp_, samples_.data(), n_complex), "sdrx_group_process");
+        }
         after_frame(n_complex);
     }
     sdrx_ctx *context() { return ctx_; }
+    sdrx_group *group() { return grp_; }
 
 private:
+    bool started() const { return ctx_ || grp_; }
+    void dc_correct(std::vector<float> &x)
+    {
+        const float keep = 1.0f - 0.000001f, k = 0.000001f;
+        for (size_t i = 0; i + 1 < x.size(); i += 2) {
+            avept_[0] = avept_[0] * keep + k * x[i];
+            avept_[1] = avept_[1] * keep + k * x[i + 1];
+            x[i] -= avept_[0];
+            x[i + 1] -= avept_[1];
+        }
+    }
+    // the context that holds VFO `id` and its id there
+    sdrx_ctx *locate(int id, int *local)
+    {
+        if (!grp_) {
+            *local = id;
+            return ctx_;
+        }
+        int member = -1;
+        sdrx_ctx *c = nullptr;
+        check(sdrx_group_locate(grp_, id, &member, local), "sdrx_group_locate");
+        check(sdrx_group_member(grp_, member, &c, nullptr), "sdrx_group_member");
+        return c;
+    }
     // vfo::process ends with `if (emitFFT) emit fftData(decimate[decimateCount])` (vfo.cpp:290-293);
     // demodData with `if (count == 4 && emitFFT) { emit fftData(samples); count = 0; } count++`.
     void after_frame(int n_complex)
     {
         for (vfo *v : all_)
             if (v->emitFFT && v->fftData) {
-                int n = 0;
-                check(sdrx_get_stream(ctx_, v->id, nullptr, 0, &n), "sdrx_get_stream");
+                int n = 0, lid = -1;
+                sdrx_ctx *c = locate(v->id, &lid);
+                check_ctx(c, sdrx_get_stream(c, lid, nullptr, 0, &n), "sdrx_get_stream");
                 tap_.resize((size_t)n);
-                check(sdrx_get_stream(ctx_, v->id, reinterpret_cast<float *>(tap_.data()), n, &n), "sdrx_get_stream");
+                check_ctx(c, sdrx_get_stream(c, lid, reinterpret_cast<float *>(tap_.data()), n, &n), "sdrx_get_stream");
                 v->fftData(tap_);
             }
         if (count == 4 && emitFFT) {
             if (fftData) {
                 int n = 0;
                 tap_.resize((size_t)n_complex);
-                check(sdrx_get_raw(ctx_, reinterpret_cast<float *>(tap_.data()), n_complex, &n), "sdrx_get_raw");
-                tap_.resize((size_t)n);
-                fftData(tap_);
+                if (grp_) { // the frame as the host handed it over (after its own LUT / DC removal)
+                    if (samples_.size() == (size_t)2 * n_complex)
+                        std::memcpy(static_cast<void *>(tap_.data()), samples_.data(), sizeof(float) * samples_.size());
+                    else
+                        tap_.clear();
+                } else {
+                    check(sdrx_get_raw(ctx_, reinterpret_cast<float *>(tap_.data()), n_complex, &n), "sdrx_get_raw");
+                    tap_.resize((size_t)n);
+                }
+                if (!tap_.empty())
+                    fftData(tap_);
             }
             count = 0;
         }
@@ -178,7 +247,10 @@ private:
         if (!v->initialised)
             throw std::runtime_error("vfo::init was not called");
         v->d.parent_id = parent;
-        check(sdrx_add_vfo(ctx_, &v->d, &v->id), "sdrx_add_vfo");
+        if (grp_)
+            check(sdrx_group_add_vfo(grp_, &v->d, &v->id), "sdrx_group_add_vfo");
+        else
+            check(sdrx_add_vfo(ctx_, &v->d, &v->id), "sdrx_add_vfo");
         if (v->mpVFOs)
             for (vfo *c : *v->mpVFOs)
                 add(c, v->id);
@@ -186,7 +258,12 @@ private:
     void check(int rc, const char *what)
     {
         if (rc != SDRX_OK)
-            throw std::runtime_error(std::string(what) + ": " + sdrx_last_error(ctx_));
+            throw std::runtime_error(std::string(what) + ": " + (grp_ ? sdrx_group_last_error(grp_) : sdrx_last_error(ctx_)));
+    }
+    static void check_ctx(sdrx_ctx *c, int rc, const char *what)
+    {
+        if (rc != SDRX_OK)
+            throw std::runtime_error(std::string(what) + ": " + sdrx_last_error(c));
     }
     static void trampoline(void *user, const char topic[5], uint32_t rate, const void *buf, uint32_t len)
     {
@@ -194,8 +271,9 @@ private:
         if (self->publish_)
             self->publish_(topic, rate, buf, len);
     }
-    int device_;
+    std::vector<int> devices_;
     sdrx_ctx *ctx_ = nullptr;
+    sdrx_group *grp_ = nullptr;
     std::vector<vfo *> *mpVFOs = nullptr;
     bool correctDC = false;
     bool emitFFT = false;

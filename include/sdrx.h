@@ -84,11 +84,12 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
  *   "keep_prequant" 1: also keep the pre-quantisation float `usb*gain*32768` per leaf
  *            (parity tests; sdrx_get_prequant).   default 0
  *   "segments" n: force n time-segments per VFO-frame in the decimation kernel (0 = auto).
- *   "pipeline" 1 (default): the leaf tail of a frame (late decimation, USB demodulation,
- *            compress) runs on a second HIP stream, so that it overlaps the mix/decimate launches
- *            of the NEXT frame when frames are queued back to back (sdrx_submit* or
- *            sdrx_process_device without a fetch in between); ordering between the two streams
- *            is by HIP events, results are bit-identical.  0: everything on one stream in order.
+ *   "pipeline" 0 (default) | 1: with 1 the leaf tail of a frame (late decimation, USB
+ *            demodulation, compress) runs on a second HIP stream behind an event, so that it may
+ *            overlap the mix/decimate launches of the NEXT frame when frames are queued back to
+ *            back; results are bit-identical.  Measured on MI355X (profiles/README.md): the two
+ *            kernels then share a VALU-bound machine and both stretch -- 0.119 vs 0.109 ms per
+ *            frame on BASELINE config 3 -- so it is off by default and kept as an A/B switch.
  *   "dc_blocked_scan" 0|1 (default 0): how sdrx_process_u8 removes the DC bias.  0 = the
  *                 reference's sequentially rounded fp32 recurrence, bit for bit (one wave,
  *                 ~1.7 ms per 384 000-sample frame).  1 = the same linear filter as a blocked
@@ -105,6 +106,13 @@ int sdrx_set_option(sdrx_ctx *ctx, const char *name, int value);
  * samples_per_buffer equals its parent's samples_per_buffer / 2^decimate_count. */
 int sdrx_finalize(sdrx_ctx *ctx);
 int sdrx_set_publish_callback(sdrx_ctx *ctx, sdrx_publish_fn fn, void *user);
+/* What vfo::init would do with this descriptor, decided on the host without touching a device (so a
+ * binding can fail at init() time exactly where the reference does): SDRX_OK; SDRX_EFILTER where
+ * firfilter::sanity_check_1f throws std::out_of_range (firfilter.cpp:122-134) -- `msg` then holds the
+ * reference's what() text, e.g. "firdes check failed: 0 < fa <= sampling_freq / 2"; SDRX_EINVAL /
+ * SDRX_EUNSUPPORTED for descriptors sdrx_add_vfo / sdrx_finalize refuse (`msg` says why).  `msg` may
+ * be NULL. */
+int sdrx_check_vfo(const sdrx_vfo_desc *desc, char *msg, size_t msg_cap);
 
 /* ---- per frame ( = sdrj::demodData, sdrj.cpp:266-305) ---------------------------------------- */
 /* `iq`: n_complex interleaved (I,Q) float pairs on the HOST, as sdr::audio_signal_out /
@@ -127,8 +135,8 @@ int sdrx_fetch(sdrx_ctx *ctx);
 int sdrx_sync(sdrx_ctx *ctx);
 /* Run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the context's
  * own; NULL restores the default.  The frame is consumed on that stream (work the caller queues on
- * it after sdrx_process_device may overwrite the frame); the leaf tail may run on a stream of the
- * library's own (option "pipeline"), which sdrx_sync / sdrx_fetch / sdrx_wait also wait for. */
+ * it after sdrx_process_device may overwrite the frame); with option "pipeline" the leaf tail runs
+ * on a stream of the library's own, which sdrx_sync / sdrx_fetch / sdrx_wait also wait for. */
 int sdrx_set_stream(sdrx_ctx *ctx, void *hip_stream);
 
 /* ---- pipelined per-frame interface ("optional async submit/wait pair") ---------------
@@ -171,6 +179,47 @@ int sdrx_get_taps(sdrx_ctx *ctx, int id, int which, float *out, int max, int *n)
 /* NCO table entries [first, first+count) of node `id` as the device generated them. */
 int sdrx_get_nco(sdrx_ctx *ctx, int id, long first, long count, float *out_iq);
 
+/* ---- one tree on several GPUs, one host process ---------------------------------------------------
+ * The fan-out the reference does on one thread -- sdrj::demodData over the main VFOs (sdrj.cpp:288-294),
+ * each main over its sub VFOs (vfo.cpp:253-264) -- sharded over the devices of one node:
+ * a group owns one sdrx_ctx per device.  sdrx_group_add_vfo describes the WHOLE tree exactly like
+ * sdrx_add_vfo; sdrx_group_finalize gives device k of W, for every parent-less VFO with children, the
+ * block [K k / W, K (k+1) / W) of its K children together with everything below them, plus a replica of
+ * the parent where that block is not empty (parent-less leaves are block-partitioned among themselves).
+ * Per frame the raw IQ lands on the FIRST device of the list and is fanned out to the others by one
+ * peer-to-peer copy each (hipMemcpyPeerAsync on the receiving device's stream: over xGMI every peer is
+ * one direct link from the source, the copies run on different links at once), double-buffered by frame
+ * parity; every device then runs its shard and copies its payloads back itself.  The publish callback is
+ * invoked in the reference's order over the whole tree, whichever device computed a leaf.  Ids are those
+ * of sdrx_group_add_vfo.  `devices` may name a device more than once (two shards on one GPU: tests).
+ * sdrx_group_submit* / _wait / _process mirror sdrx_submit* / sdrx_wait / sdrx_process.  For
+ * sdrx_group_submit_device the frame (cf32, on the first device) must be complete in the order of
+ * `producer_stream` (a hipStream_t of that device; NULL: complete already) and stay untouched until
+ * it was waited for.  A device that ends up without VFOs (more devices than sub VFOs) stays idle. */
+typedef struct sdrx_group sdrx_group;
+int sdrx_group_create(sdrx_group **grp, const int *device_ordinals, int n_devices);
+int sdrx_group_destroy(sdrx_group *grp);
+const char *sdrx_group_last_error(const sdrx_group *grp); /* grp may be NULL: error of a failed create */
+int sdrx_group_size(const sdrx_group *grp);
+int sdrx_group_add_vfo(sdrx_group *grp, const sdrx_vfo_desc *desc, int *id_out);
+int sdrx_group_set_option(sdrx_group *grp, const char *name, int value); /* applied to every member */
+int sdrx_group_set_publish_callback(sdrx_group *grp, sdrx_publish_fn fn, void *user);
+int sdrx_group_finalize(sdrx_group *grp);
+int sdrx_group_process(sdrx_group *grp, const float *iq, int n_complex);
+int sdrx_group_submit(sdrx_group *grp, const float *iq, int n_complex);
+int sdrx_group_submit_u8(sdrx_group *grp, const uint8_t *iq_bytes, int n_complex);
+int sdrx_group_submit_device(sdrx_group *grp, const void *dev_iq_on_first_device, int n_complex, void *producer_stream);
+int sdrx_group_wait(sdrx_group *grp);
+int sdrx_group_in_flight(sdrx_group *grp);
+int sdrx_group_sync(sdrx_group *grp);
+int sdrx_group_get_output(sdrx_group *grp, int id, const void **buf, uint32_t *len_bytes, uint32_t *rate);
+/* Where a VFO lives: *member = index into the device list (the owner of a leaf; the first replica of
+ * a VFO with children), *local_id = its id inside that member's context; sdrx_group_member hands out
+ * that context (NULL for a member that holds no VFOs) for sdrx_get_stream / sdrx_get_stats / kernel
+ * timing. */
+int sdrx_group_locate(sdrx_group *grp, int id, int *member, int *local_id);
+int sdrx_group_member(sdrx_group *grp, int k, sdrx_ctx **ctx, int *device_ordinal);
+
 /* ---- introspection / measurement ------------------------------------------------------------- */
 typedef struct sdrx_stats {
     int32_t n_vfos, n_leaves, n_levels;
@@ -187,7 +236,7 @@ int sdrx_get_stats(sdrx_ctx *ctx, sdrx_stats *out);
  * kernel launch with events (small overhead: use for profiling runs, not for throughput runs).
  * sdrx_get_kernel_times: accumulated milliseconds and launch counts since enabling, for
  * kernel kinds 0..SDRX_NKERNELS-1 (names from sdrx_kernel_name). */
-#define SDRX_NKERNELS 6
+#define SDRX_NKERNELS 7
 int sdrx_enable_kernel_timing(sdrx_ctx *ctx, int enable);
 int sdrx_get_kernel_times(sdrx_ctx *ctx, double ms[SDRX_NKERNELS], int64_t launches[SDRX_NKERNELS],
                           int64_t alg_bytes[SDRX_NKERNELS]);

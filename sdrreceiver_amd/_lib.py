@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDRX_LIB") or os.path.join(_HERE, "libsdrx.so")  # SDRX_LIB: A/B builds of the SAME HIP library
 CSRC = os.path.join(_HERE, "csrc")
 
-NKERNELS = 6
+NKERNELS = 7
 
 
 class VfoDescC(C.Structure):
@@ -53,6 +53,7 @@ SYMBOLS = {
     "sdrx_set_option": (_i, [_vp, C.c_char_p, _i]),
     "sdrx_finalize": (_i, [_vp]),
     "sdrx_set_publish_callback": (_i, [_vp, PUBLISH_FN, _vp]),
+    "sdrx_check_vfo": (_i, [C.POINTER(VfoDescC), C.c_char_p, C.c_size_t]),
     "sdrx_process": (_i, [_vp, _vp, _i]),
     "sdrx_process_u8": (_i, [_vp, _vp, _i, _i]),
     "sdrx_process_device": (_i, [_vp, _vp, _i]),
@@ -70,6 +71,24 @@ SYMBOLS = {
     "sdrx_get_prequant": (_i, [_vp, _i, _vp, _i, C.POINTER(_i)]),
     "sdrx_get_taps": (_i, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "sdrx_get_nco": (_i, [_vp, _i, C.c_long, C.c_long, _vp]),
+    "sdrx_group_create": (_i, [C.POINTER(_vp), C.POINTER(_i), _i]),
+    "sdrx_group_destroy": (_i, [_vp]),
+    "sdrx_group_last_error": (C.c_char_p, [_vp]),
+    "sdrx_group_size": (_i, [_vp]),
+    "sdrx_group_add_vfo": (_i, [_vp, C.POINTER(VfoDescC), C.POINTER(_i)]),
+    "sdrx_group_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "sdrx_group_set_publish_callback": (_i, [_vp, PUBLISH_FN, _vp]),
+    "sdrx_group_finalize": (_i, [_vp]),
+    "sdrx_group_process": (_i, [_vp, _vp, _i]),
+    "sdrx_group_submit": (_i, [_vp, _vp, _i]),
+    "sdrx_group_submit_u8": (_i, [_vp, _vp, _i]),
+    "sdrx_group_submit_device": (_i, [_vp, _vp, _i, _vp]),
+    "sdrx_group_wait": (_i, [_vp]),
+    "sdrx_group_in_flight": (_i, [_vp]),
+    "sdrx_group_sync": (_i, [_vp]),
+    "sdrx_group_get_output": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "sdrx_group_locate": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "sdrx_group_member": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i)]),
     "sdrx_get_stats": (_i, [_vp, C.POINTER(StatsC)]),
     "sdrx_enable_kernel_timing": (_i, [_vp, _i]),
     "sdrx_get_kernel_times": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -25,6 +25,17 @@ namespace sdrx {
 // all point into HBM: these helpers say so, so that accesses become global_load/global_store
 // (or s_load for wave-uniform read-only data) instead of flat_* instructions.
 #define SDRX_AS1 __attribute__((address_space(1)))
+// Descriptors, work lists and filter taps are written once at sdrx_finalize and never by a kernel:
+// reading them through the CONSTANT address space tells the compiler so (no store of the kernel can
+// alias them), and a wave-uniform address then becomes a scalar load into SGPRs whatever else the
+// kernel does.  (Without it the 62 Hilbert taps of the demodulation turn into 62 VGPRs -- and spill --
+// as soon as the same kernel also contains the mix/decimate code: k_frame.)
+#define SDRX_AS4 __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ T ldc(const T *p)
+{
+    return *(const SDRX_AS4 T *)p;
+}
 using v2f = float __attribute__((ext_vector_type(2)));
 using v4f = float __attribute__((ext_vector_type(4)));
 using v4s = short __attribute__((ext_vector_type(4)));
@@ -468,33 +479,31 @@ __device__ __forceinline__ void hb_regs(const v2f *ext, v2f *y)
 // halo slot q (0..7) <-> distance k back from the lane's first sample: -10,-8,-6,-5,-4,-3,-2,-1
 __device__ __forceinline__ constexpr int halo_k(int q) { return q == 0 ? 10 : q == 1 ? 8 : q == 2 ? 6 : 8 - q; }
 
-// Fused NCO + mixer + half-band cascade.  One wave per workgroup, one workgroup per K1Work.
-// LEVEL only gives the root launch and the sub launches distinct kernel names in profiles.
+// Fused NCO + mixer + half-band cascade.
 #ifndef SDRX_K1_MIN_WAVES
 #define SDRX_K1_MIN_WAVES 5 // waves per SIMD the register allocator must leave room for
 #endif
-template <bool EXACT, int LEVEL>
-__global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1Vfo *__restrict__ vfos, const K1Work *__restrict__ work,
-                                                     unsigned long long frame_no, const void *__restrict__ raw, int raw_mode)
+// The body of one work item, run by ONE wave on LDS of its own (`smem`: k1_lds_bytes()); `level0`: the
+// item's VFO is fed by the raw frame (`raw`, `raw_mode`), otherwise by its parent's tile-layout stream.
+template <bool EXACT>
+__device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K1Work W, unsigned long long frame_no,
+                                         const void *__restrict__ raw, int raw_mode, bool level0, unsigned char *smem, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     v2f *car0 = reinterpret_cast<v2f *>(smem);             // [8]
     v2f *car1 = car0 + 8;                                  // [8]
     v2f *lds = reinterpret_cast<v2f *>(smem + kCarryBytes);
 
-    const K1Work W = work[blockIdx.x];
-    const int lane = threadIdx.x;
     const int par = (int)(frame_no & 1ull);
     const K1Vfo *Dp = vfos + W.vfo;
     struct {
         const float2 *cp;
         int n_in, d, L, out_tiled;
-    } D = {Dp->cp, Dp->n_in, Dp->d, Dp->L, Dp->out_tiled};
-    const v2f rot = {Dp->rot_re, Dp->rot_im};
-    const float4 *in = reinterpret_cast<const float4 *>(Dp->in[par]);
-    float2 *out = Dp->out[par];
-    const float2 *hb_load = Dp->hb[par];
-    float2 *hb_save = Dp->hb[par ^ 1];
+    } D = {ldc(&Dp->cp), ldc(&Dp->n_in), ldc(&Dp->d), ldc(&Dp->L), ldc(&Dp->out_tiled)};
+    const v2f rot = {ldc(&Dp->rot_re), ldc(&Dp->rot_im)};
+    const float4 *in = reinterpret_cast<const float4 *>(ldc(&Dp->in[par]));
+    float2 *out = ldc(&Dp->out[par]);
+    const float2 *hb_load = ldc(&Dp->hb[par]);
+    float2 *hb_save = ldc(&Dp->hb[par ^ 1]);
     const bool from_state = W.s_begin == 0;
     const v2f zero2 = {0.f, 0.f};
 
@@ -534,7 +543,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
         // 1. this lane's run of 16 consecutive samples: 8 coalesced 16-byte loads
         v2f ext0[10 + kRun]; // ext0[10 + t] = x[t]; ext0[0..9] = halo x[-10..-1]
         v2f *x = ext0 + 10;
-        if (LEVEL == 0 && raw_mode == kRawF32) {
+        if (level0 && raw_mode == kRawF32) {
             // the caller's frame as it is (natural order): each lane reads its own 128 contiguous
             // bytes.  Uncoalesced across the wave, but a level of 2-3 main VFOs is latency bound
             // and this saves the layout pass over the raw frame.
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
                 x[2 * i] = lo2(v);
                 x[2 * i + 1] = hi2(v);
             }
-        } else if (LEVEL == 0 && raw_mode == kRawU8) {
+        } else if (level0 && raw_mode == kRawU8) {
             // dongle bytes: floats[b] = b - 127 (jonti/sdr.cpp:43-49), 32 bytes per lane
             const v4u *nat = reinterpret_cast<const v4u *>(raw) + (size_t)p16 * 2;
 #pragma unroll
@@ -767,6 +776,16 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
     }
 }
 
+// One wave per workgroup, one workgroup per K1Work.  LEVEL only gives the root launch and the sub
+// launches distinct kernel names in profiles.
+template <bool EXACT, int LEVEL>
+__global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1Vfo *__restrict__ vfos, const K1Work *__restrict__ work,
+                                                     unsigned long long frame_no, const void *__restrict__ raw, int raw_mode)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    mix_item<EXACT>(vfos, work[blockIdx.x], frame_no, raw, raw_mode, LEVEL == 0, smem, (int)threadIdx.x);
+}
+
 // ------------------------------------------------------------------------------------ demod tail
 // `short = double` of the reference's x86-64 build (vfo.cpp:328,364): truncate toward zero to
 // int32, keep the low 16 bits.  v_cvt_i32_f64 truncates and saturates; in-range values (all
@@ -979,29 +998,33 @@ __global__ __launch_bounds__(64, SDRX_LATE4_WAVES) void k_late_decimate4(const K
 constexpr int kDemodTile = 1024;
 constexpr int kPlaneLen = (kDemodTile + kMaxFir + kHilbert + 1) / 2 + 8;
 
+struct DemodLds { // LDS of one 256-thread demodulation block
+    alignas(16) float sP0[kPlaneLen + 4]; // even offsets from `lo`, stored shifted by +3
+    alignas(16) float sP1[kPlaneLen + 4]; // odd offsets
+    alignas(16) float sI[kDemodTile + kMaxFir + 8];
+    alignas(16) float sU[kDemodTile + kMaxFir + 16];
+    alignas(16) float sH[kMaxFir + 16];
+};
+static_assert(sizeof(DemodLds) % 16 == 0, "DemodLds is a whole number of 16-byte units");
+
 template <bool EXACT>
-__global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfos, const BlockWork *__restrict__ work,
-                                                   unsigned long long frame_no)
+__device__ __forceinline__ void demod_block(const K2Vfo *__restrict__ vfos, const BlockWork bw, unsigned long long frame_no, DemodLds &S,
+                                            int tid)
 {
-    __shared__ __attribute__((aligned(16))) float sP0[kPlaneLen + 4]; // even offsets from `lo`, stored shifted by +3
-    __shared__ __attribute__((aligned(16))) float sP1[kPlaneLen + 4]; // odd offsets
-    __shared__ __attribute__((aligned(16))) float sI[kDemodTile + kMaxFir + 8];
-    __shared__ __attribute__((aligned(16))) float sU[kDemodTile + kMaxFir + 16];
-    __shared__ __attribute__((aligned(16))) float sH[kMaxFir + 16];
-    const BlockWork bw = work[blockIdx.x];
+    float *sP0 = S.sP0, *sP1 = S.sP1, *sI = S.sI, *sU = S.sU, *sH = S.sH;
     const K2Vfo *Dp = vfos + bw.vfo;
     const int blk = bw.blk;
     const int par = (int)(frame_no & 1ull);
-    const int tid = threadIdx.x;
     struct {
         const float *hnz, *lpf;
         short *pay;
         float *prequant;
         float gain;
         int H, n, nlpf, tile;
-    } D = {Dp->hnz, Dp->lpf_pad, Dp->pay[par], Dp->prequant, Dp->gain, Dp->H, Dp->n, Dp->nlpf, Dp->tile};
-    const float2 *sbase = Dp->s[par];
-    float2 *snext = Dp->s_next[par];
+    } D = {ldc(&Dp->hnz), ldc(&Dp->lpf_pad), ldc(&Dp->pay[par]), ldc(&Dp->prequant), ldc(&Dp->gain),
+           ldc(&Dp->H),   ldc(&Dp->n),       ldc(&Dp->nlpf),     ldc(&Dp->tile)};
+    const float2 *sbase = ldc(&Dp->s[par]);
+    float2 *snext = ldc(&Dp->s_next[par]);
     const int m0 = blk * D.tile;
     if (m0 >= D.n && blk != 0)
         return;
@@ -1010,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfo
     float hnz[kHilbertNz];
 #pragma unroll
     for (int s = 0; s < kHilbertNz; ++s)
-        hnz[s] = gld(D.hnz + s);
+        hnz[s] = ldc(D.hnz + s);
     if (D.nlpf > 0)
         for (int j = tid; j < D.nlpf + 15; j += 256)
             sH[j] = gld(D.lpf + j);
@@ -1139,6 +1162,43 @@ __global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfo
                 *(SDRX_AS1 float *)(D.prequant + m + rr) = pq[rr];
         }
     }
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfos, const BlockWork *__restrict__ work,
+                                                   unsigned long long frame_no)
+{
+    __shared__ __attribute__((aligned(16))) DemodLds S;
+    demod_block<EXACT>(vfos, work[blockIdx.x], frame_no, S, (int)threadIdx.x);
+}
+
+// ------------------------------------------------------------------------------------ k_mix_levels
+// ONE launch for the mix/decimate items of EVERY tree level, each level working on the frame that has
+// reached it: level l on frame k - l (a software pipeline over consecutive frames: the levels of one
+// launch are independent of each other).  Why: on BASELINE config 3 the level-0 launch -- 2-3 main VFOs,
+// ~770 one-chunk items -- leaves most of the chip idle for its whole duration (6-9 us of a ~110 us
+// frame); as part of the same grid its short items run beside the sub VFOs' long ones, without the
+// cross-stream events that cost more than they gain on this runtime (profiles/README.md).
+// The list is [level 0 items | level 1 items | ...], every part starting at a multiple of 8 entries
+// (workgroup i runs on XCD i mod 8: a part keeps its XCD mapping whichever range a launch covers);
+// -1 = padding.  One wave per workgroup, exactly as k_mix_decimate.
+struct LevelArgs {
+    unsigned long long frame_level[kMaxLevels]; // frame each tree level works on in this launch
+    const void *raw;                            // level 0's raw frame ...
+    int raw_mode;                               // ... and its form (kRaw*)
+    int pad_;
+};
+template <bool EXACT>
+__global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_levels(const K1Vfo *__restrict__ k1, const K1Work *__restrict__ items,
+                                                   const int *__restrict__ item_level, const int *__restrict__ list, LevelArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int it = ldc(list + blockIdx.x);
+    if (it < 0)
+        return;
+    const int lv = ldc(item_level + it);
+    mix_item<EXACT>(k1, K1Work{ldc(&items[it].vfo), ldc(&items[it].s_begin), ldc(&items[it].s_first_out), ldc(&items[it].s_end)},
+                    A.frame_level[lv], A.raw, A.raw_mode, lv == 0, smem, (int)threadIdx.x);
 }
 
 // vfo::compress (vfo.cpp:389-424): cstyle 1 packs the high nibbles of (re/scalecomp)*128 and

@@ -37,9 +37,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Kind { KIND_MIX_ROOT = 0, KIND_MIX_SUB = 1, KIND_LATE_DEC = 2, KIND_DEMOD = 3, KIND_COMPRESS = 4, KIND_INGEST = 5 };
-const char *kKindNames[SDRX_NKERNELS] = {"k_mix_decimate(level0)", "k_mix_decimate(sub)", "k_late_decimate",
-                                         "k_usb_demod",            "k_compress",          "k_ingest"};
+enum Kind { KIND_MIX_ROOT = 0, KIND_MIX_SUB = 1, KIND_LATE_DEC = 2, KIND_DEMOD = 3, KIND_COMPRESS = 4, KIND_INGEST = 5, KIND_LEVELS = 6 };
+const char *kKindNames[SDRX_NKERNELS] = {"k_mix_decimate(level0)", "k_mix_decimate(sub)", "k_late_decimate", "k_usb_demod",
+                                         "k_compress",             "k_ingest",            "k_mix_levels"};
 
 struct Node {
     sdrx_vfo_desc d;
@@ -78,6 +78,21 @@ struct LaunchB { // block-per-tile launches (late decimate / demod / compress): 
     int64_t alg_bytes;
 };
 
+// The one-launch levels (k_mix_levels): the list is [level 0 items | level 1 items | ...], every part
+// starting at a multiple of 8 entries.  A launch covers the contiguous range of the levels that have a
+// frame to work on.
+struct LevelPlan {
+    bool usable = false;
+    size_t off_items = 0, off_item_level = 0, off_list = 0; // arena offsets
+    std::vector<int> part_begin, part_end;                   // list range of every level
+    std::vector<int64_t> part_bytes;                         // SURVEY 8d share of every level
+    int lds_bytes = 0;
+};
+struct InFlight { // a frame inside the software pipeline: `next` = the level that runs it in the next launch
+    unsigned long long f;
+    int next;
+};
+
 struct TimedEvent {
     hipEvent_t a, b;
     int kind;
@@ -91,13 +106,16 @@ struct sdrx_ctx {
     std::string err;
     std::vector<Node> nodes;
     bool finalized = false;
-    int opt_exact = 1, opt_prequant = 0, opt_segments = 0, opt_dc_blocked = 0, opt_pipeline = 1;
+    int opt_exact = 1, opt_prequant = 0, opt_segments = 0, opt_dc_blocked = 0, opt_pipeline = 0;
+    int opt_fuse = 1, opt_frame_pipeline = 1;
+    LevelPlan fp;
+    std::vector<InFlight> pipe; // oldest first
     sdrx_publish_fn cb = nullptr;
     void *cb_user = nullptr;
 
     // Streams.  `stream` (the context's own or the caller's) carries the ingest and the
     // mix/decimate launches of every tree level; the leaf tail of a frame runs on `tail_stream`
-    // when option "pipeline" is on, so that it overlaps the next frame's levels; payloads leave on
+    // when option "pipeline" is on (off by default: measured slower, profiles/README.md); payloads leave on
     // `copy_stream` for frames that came in through sdrx_submit*.  Cross-stream order is by the
     // per-parity events below (measured on this runtime, tools/event_probe.hip: a record costs its
     // stream ~3-5 us, a wait on an event that completed long ago ~2.5 us, a tight hop ~11 us).
@@ -252,6 +270,11 @@ struct Bracket { // RAII: event pair around one launch when timing is on, on the
     }
 };
 
+int pipeline_step(sdrx_ctx *c, bool have_new, const void *raw, int raw_mode);
+int pipeline_flush(sdrx_ctx *c);
+inline int pipeline_flush_unless(sdrx_ctx *c, bool keep) { return keep ? SDRX_OK : pipeline_flush(c); }
+void launch_block_kernel(sdrx_ctx *c, const LaunchB &L, hipStream_t ts, unsigned long long frame, bool exact);
+
 // One frame: [wait for the tail of frame f-2] -> ingest -> one k_mix_decimate launch per tree level on
 // `stream`; then the leaf tail (late decimation, demodulation, compress) -- on `tail_stream` behind an
 // event when the pipeline option is on, so that it runs beside the NEXT frame's levels -- and, for a
@@ -287,6 +310,23 @@ int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode, bool egress)
                                reinterpret_cast<const unsigned *>(raw), reinterpret_cast<float4 *>(c->d_raw_tiled), n_pairs);
         raw_mode = kRawTiled;
     }
+    if (int rc = pipeline_flush_unless(c, c->fp.usable && c->opt_fuse && !pipe && !egress))
+        return rc;
+    if (c->fp.usable && c->opt_fuse && !pipe && !egress) {
+        // Frames that stay on the device and are queued back to back share launches: level l of frame
+        // k - l runs in the launch that frame k enters with, and the frame that leaves the last level
+        // gets its leaf tail right behind it.  (A frame whose payloads must leave now -- sdrx_process*,
+        // sdrx_submit* -- runs through its own launches below: nothing to overlap it with.)
+        const int rc = pipeline_step(c, true, raw, raw_mode);
+        if (rc)
+            return rc;
+        if (!c->opt_frame_pipeline)
+            if (int rc2 = pipeline_flush(c))
+                return rc2;
+        c->frame_no++;
+        c->pending_fetch = true;
+        return SDRX_OK;
+    }
     for (const Launch1 &L : c->l1) {
         Bracket b(c, c->stream, L.kind, L.alg_bytes);
         const K1Work *w = reinterpret_cast<const K1Work *>(c->arena + L.off_work);
@@ -301,27 +341,8 @@ int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode, bool egress)
         HIPCHK(c, hipEventRecord(c->ev_levels[p], c->stream));
         HIPCHK(c, hipStreamWaitEvent(ts, c->ev_levels[p], 0));
     }
-    for (const LaunchB &L : c->lb) {
-        Bracket b(c, ts, L.kind, L.alg_bytes);
-        const dim3 grid(L.n_blocks);
-        const BlockWork *w = reinterpret_cast<const BlockWork *>(c->arena + L.off_work);
-        if (L.kind == KIND_LATE_DEC && c->late4)
-            if (c->late4_r == 2)
-                hipLaunchKernelGGL((k_late_decimate4<EXACT, 2>), grid, dim3(64), L.lds_bytes, ts,
-                                   reinterpret_cast<const K2aVfo *>(c->arena + L.off_desc), w, c->frame_no);
-            else
-                hipLaunchKernelGGL((k_late_decimate4<EXACT, 4>), grid, dim3(64), L.lds_bytes, ts,
-                                   reinterpret_cast<const K2aVfo *>(c->arena + L.off_desc), w, c->frame_no);
-        else if (L.kind == KIND_LATE_DEC)
-            hipLaunchKernelGGL(k_late_decimate<EXACT>, grid, dim3(256), L.lds_bytes, ts,
-                               reinterpret_cast<const K2aVfo *>(c->arena + L.off_desc), w, c->frame_no);
-        else if (L.kind == KIND_DEMOD)
-            hipLaunchKernelGGL(k_usb_demod<EXACT>, grid, dim3(256), 0, ts,
-                               reinterpret_cast<const K2Vfo *>(c->arena + L.off_desc), w, c->frame_no);
-        else
-            hipLaunchKernelGGL(k_compress, grid, dim3(256), 0, ts,
-                               reinterpret_cast<const K3Vfo *>(c->arena + L.off_desc), w, c->frame_no);
-    }
+    for (const LaunchB &L : c->lb)
+        launch_block_kernel(c, L, ts, c->frame_no, EXACT);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(c, SDRX_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -340,9 +361,107 @@ int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode, bool egress)
     return SDRX_OK;
 }
 
-// every stream of the context is idle afterwards
+void launch_block_kernel(sdrx_ctx *c, const LaunchB &L, hipStream_t ts, unsigned long long frame, bool exact)
+{
+    Bracket b(c, ts, L.kind, L.alg_bytes);
+    const dim3 grid(L.n_blocks);
+    const BlockWork *w = reinterpret_cast<const BlockWork *>(c->arena + L.off_work);
+    const K2aVfo *k2a = reinterpret_cast<const K2aVfo *>(c->arena + L.off_desc);
+    if (L.kind == KIND_LATE_DEC && c->late4) {
+        if (c->late4_r == 2) {
+            if (exact)
+                hipLaunchKernelGGL((k_late_decimate4<true, 2>), grid, dim3(64), L.lds_bytes, ts, k2a, w, frame);
+            else
+                hipLaunchKernelGGL((k_late_decimate4<false, 2>), grid, dim3(64), L.lds_bytes, ts, k2a, w, frame);
+        } else {
+            if (exact)
+                hipLaunchKernelGGL((k_late_decimate4<true, 4>), grid, dim3(64), L.lds_bytes, ts, k2a, w, frame);
+            else
+                hipLaunchKernelGGL((k_late_decimate4<false, 4>), grid, dim3(64), L.lds_bytes, ts, k2a, w, frame);
+        }
+    } else if (L.kind == KIND_LATE_DEC) {
+        if (exact)
+            hipLaunchKernelGGL(k_late_decimate<true>, grid, dim3(256), L.lds_bytes, ts, k2a, w, frame);
+        else
+            hipLaunchKernelGGL(k_late_decimate<false>, grid, dim3(256), L.lds_bytes, ts, k2a, w, frame);
+    } else if (L.kind == KIND_DEMOD) {
+        const K2Vfo *k2 = reinterpret_cast<const K2Vfo *>(c->arena + L.off_desc);
+        if (exact)
+            hipLaunchKernelGGL(k_usb_demod<true>, grid, dim3(256), 0, ts, k2, w, frame);
+        else
+            hipLaunchKernelGGL(k_usb_demod<false>, grid, dim3(256), 0, ts, k2, w, frame);
+    } else {
+        hipLaunchKernelGGL(k_compress, grid, dim3(256), 0, ts, reinterpret_cast<const K3Vfo *>(c->arena + L.off_desc), w, frame);
+    }
+}
+
+// One step of the frame pipeline: every in-flight frame (and the new one, if `have_new`) moves through
+// the tree level it has reached -- ONE k_mix_levels launch over the contiguous range of those levels --
+// and the frame that thereby leaves the last level gets its leaf tail (late decimation, demodulation,
+// compress) right behind that launch.
+int pipeline_step(sdrx_ctx *c, bool have_new, const void *raw, int raw_mode)
+{
+    const LevelPlan &P = c->fp;
+    const int n_levels = (int)P.part_begin.size();
+    if (have_new)
+        c->pipe.push_back({c->frame_no, 0});
+    if (c->pipe.empty())
+        return SDRX_OK;
+    LevelArgs A;
+    memset(&A, 0, sizeof A);
+    A.raw = raw;
+    A.raw_mode = raw_mode;
+    int lo = n_levels, hi = -1;
+    for (const InFlight &q : c->pipe) {
+        lo = std::min(lo, q.next);
+        hi = std::max(hi, q.next);
+        A.frame_level[q.next] = q.f;
+    }
+    const int first = std::min(P.part_begin[(size_t)lo], P.part_begin[(size_t)hi]), last = std::max(P.part_end[(size_t)lo], P.part_end[(size_t)hi]);
+    {
+        int64_t bytes = 0;
+        for (int j = lo; j <= hi; ++j)
+            bytes += P.part_bytes[(size_t)j];
+        Bracket b(c, c->stream, lo != hi ? KIND_LEVELS : lo == 0 ? KIND_MIX_ROOT : KIND_MIX_SUB, bytes);
+        const K1Vfo *k1 = reinterpret_cast<const K1Vfo *>(c->arena + c->off_k1vfo);
+        const K1Work *items = reinterpret_cast<const K1Work *>(c->arena + P.off_items);
+        const int *item_level = reinterpret_cast<const int *>(c->arena + P.off_item_level);
+        const int *list = reinterpret_cast<const int *>(c->arena + P.off_list) + first;
+        if (c->opt_exact)
+            hipLaunchKernelGGL(k_mix_levels<true>, dim3(last - first), dim3(64), P.lds_bytes, c->stream, k1, items, item_level, list, A);
+        else
+            hipLaunchKernelGGL(k_mix_levels<false>, dim3(last - first), dim3(64), P.lds_bytes, c->stream, k1, items, item_level, list, A);
+    }
+    for (InFlight &q : c->pipe)
+        q.next++;
+    if (c->pipe.front().next >= n_levels) { // the oldest frame has passed its last level: its leaf tail, now
+        const unsigned long long f = c->pipe.front().f;
+        for (const LaunchB &L : c->lb)
+            launch_block_kernel(c, L, c->stream, f, c->opt_exact != 0);
+        c->pipe.erase(c->pipe.begin());
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(c, SDRX_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return SDRX_OK;
+}
+
+// run every in-flight frame to its end
+int pipeline_flush(sdrx_ctx *c)
+{
+    while (!c->pipe.empty()) {
+        const int rc = pipeline_step(c, false, nullptr, kRawTiled);
+        if (rc)
+            return rc;
+    }
+    return SDRX_OK;
+}
+
+// every frame handed to the context is complete and every stream of the context idle afterwards
 int drain(sdrx_ctx *c)
 {
+    if (int rc = pipeline_flush(c))
+        return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->tail_stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
@@ -502,6 +621,10 @@ int sdrx_set_option(sdrx_ctx *c, const char *name, int value)
         c->opt_dc_blocked = value != 0;
     else if (!strcmp(name, "pipeline"))
         c->opt_pipeline = value != 0;
+    else if (!strcmp(name, "fuse"))
+        c->opt_fuse = value != 0;
+    else if (!strcmp(name, "frame_pipeline"))
+        c->opt_frame_pipeline = value != 0;
     else
         return fail(c, SDRX_EINVAL, "unknown option '%s'", name);
     return SDRX_OK;
@@ -531,6 +654,44 @@ int sdrx_add_vfo(sdrx_ctx *c, const sdrx_vfo_desc *d, int *id_out)
         c->nodes[(size_t)d->parent_id].children.push_back(id);
     if (id_out)
         *id_out = id;
+    return SDRX_OK;
+}
+
+int sdrx_check_vfo(const sdrx_vfo_desc *d, char *msg, size_t cap)
+{
+    auto say = [&](int code, const char *fmt, ...) {
+        if (msg && cap) {
+            va_list ap;
+            va_start(ap, fmt);
+            vsnprintf(msg, cap, fmt, ap);
+            va_end(ap);
+        }
+        return code;
+    };
+    if (!d)
+        return SDRX_EINVAL;
+    if (msg && cap)
+        msg[0] = 0;
+    if (d->decimate_count < 0 || d->decimate_count > kMaxStages)
+        return say(SDRX_EINVAL, "decimate_count %d outside 0..8 (vfo.h:63)", d->decimate_count);
+    if (d->fs <= 0 || d->samples_per_buffer <= 0)
+        return say(SDRX_EINVAL, "fs and samples_per_buffer must be positive");
+    if (d->late_decimate < 0 || d->late_decimate == 1)
+        return say(SDRX_EINVAL, "late_decimate must be 0 or >= 2 (the reference uses 5 and 6)");
+    // the order of vfo::init (vfo.cpp:60-124): late-decimation low-pass first, then the audio low-pass
+    int target = (int)(d->fs / std::pow(2, d->decimate_count));
+    if (d->demod_usb && d->late_decimate > 0) {
+        target /= d->late_decimate;
+        if (const char *why = low_pass_rejection((double)target * d->late_decimate, (double)(target / 2), (double)target / (d->late_decimate - 1)))
+            return say(SDRX_EFILTER, "%s", why);
+    }
+    if (d->demod_usb && d->filter_bw_hz > 0)
+        if (const char *why = low_pass_rejection((double)target, (double)d->filter_bw_hz, (double)d->filter_bw_hz / 4))
+            return say(SDRX_EFILTER, "%s", why);
+    if (d->fs % kRun || d->samples_per_buffer % kRun || d->fs < kChunk)
+        return say(SDRX_EUNSUPPORTED, "fs (%d) and samples_per_buffer (%d) must be multiples of 16 and fs >= 1024", d->fs, d->samples_per_buffer);
+    if (d->samples_per_buffer % (1 << d->decimate_count))
+        return say(SDRX_EUNSUPPORTED, "samples_per_buffer %d not a multiple of 2^%d", d->samples_per_buffer, d->decimate_count);
     return SDRX_OK;
 }
 
@@ -895,6 +1056,40 @@ static int finalize_impl(sdrx_ctx *c)
         ow3 = plan.take(sizeof(BlockWork) * w3.size());
         c->lb.push_back({KIND_COMPRESS, (int)w3.size(), o3, ow3, 0, b3});
     }
+    // ---- the one-launch levels (k_mix_levels): unified item array and list
+    std::vector<K1Work> all_items;
+    std::vector<int> all_item_level, llist;
+    {
+        LevelPlan &P = c->fp;
+        P = LevelPlan();
+        P.usable = c->n_levels >= 2 && c->n_levels <= kMaxLevels; // (one level: nothing to share a launch with)
+        if (P.usable) {
+            // deepest level first: in the steady state of the reference's two-level trees the long sub-VFO
+            // items are dispatched first and the short level-0 items fill the launch's tail
+            // (SDRX_LEVEL_ORDER=1: level 0 first, for A/B runs)
+            const bool root_first = getenv("SDRX_LEVEL_ORDER") && atoi(getenv("SDRX_LEVEL_ORDER")) == 1;
+            P.part_begin.assign((size_t)c->n_levels, 0);
+            P.part_end.assign((size_t)c->n_levels, 0);
+            P.part_bytes.assign((size_t)c->n_levels, 0);
+            for (int q = 0; q < c->n_levels; ++q) {
+                const int lv = root_first ? q : c->n_levels - 1 - q;
+                while (llist.size() % 8)
+                    llist.push_back(-1);
+                P.part_begin[(size_t)lv] = (int)llist.size();
+                const int base = (int)all_items.size(), cnt = (int)works[(size_t)lv].size();
+                all_items.insert(all_items.end(), works[(size_t)lv].begin(), works[(size_t)lv].end());
+                all_item_level.insert(all_item_level.end(), (size_t)cnt, lv);
+                for (int i = 0; i < cnt; ++i)
+                    llist.push_back(base + i);
+                P.part_end[(size_t)lv] = (int)llist.size();
+                P.part_bytes[(size_t)lv] = c->l1[(size_t)lv].alg_bytes;
+                P.lds_bytes = std::max(P.lds_bytes, c->l1[(size_t)lv].lds_bytes);
+            }
+            P.off_items = plan.take(sizeof(K1Work) * all_items.size());
+            P.off_item_level = plan.take(sizeof(int) * all_item_level.size());
+            P.off_list = plan.take(sizeof(int) * llist.size());
+        }
+    }
     const size_t off_nco_jobs = plan.take(sizeof(NcoInit) * (size_t)N);
 
     // ---- allocate, zero (= the reference's zero-initialised filter state, dsp.cpp:40-49), fill
@@ -999,6 +1194,11 @@ static int finalize_impl(sdrx_ctx *c)
     HIPCHK(c, up(ow2, w2.data(), sizeof(BlockWork) * w2.size()));
     HIPCHK(c, up(o3, d3.data(), sizeof(K3Vfo) * d3.size()));
     HIPCHK(c, up(ow3, w3.data(), sizeof(BlockWork) * w3.size()));
+    if (c->fp.usable) {
+        HIPCHK(c, up(c->fp.off_items, all_items.data(), sizeof(K1Work) * all_items.size()));
+        HIPCHK(c, up(c->fp.off_item_level, all_item_level.data(), sizeof(int) * all_item_level.size()));
+        HIPCHK(c, up(c->fp.off_list, llist.data(), sizeof(int) * llist.size()));
+    }
     for (auto &kv : tap_offsets)
         HIPCHK(c, up(kv.second, kv.first.data(), kv.first.size() * sizeof(float)));
     HIPCHK(c, hipStreamSynchronize(c->stream)); // host vectors above go out of scope
@@ -1185,10 +1385,12 @@ int sdrx_submit_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correct
 
 int sdrx_in_flight(sdrx_ctx *c) { return c ? c->in_flight : SDRX_EINVAL; }
 
-int sdrx_wait(sdrx_ctx *c)
+} // extern "C"
+
+namespace {
+// the oldest undelivered frame's payloads are in host memory afterwards (slot returned); no callbacks
+int wait_frame(sdrx_ctx *c, int *slot)
 {
-    if (!c)
-        return SDRX_EINVAL;
     if (c->in_flight <= 0)
         return fail(c, SDRX_ESTATE, "sdrx_wait: no submitted frame is in flight");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1197,8 +1399,24 @@ int sdrx_wait(sdrx_ctx *c)
     HIPCHK(c, hipEventSynchronize(c->ev_copied[p]));
     c->in_flight--;
     c->delivered = f + 1;
+    c->host_slot = p;
     if (c->in_flight == 0)
         drain_events(c);
+    *slot = p;
+    return SDRX_OK;
+}
+} // namespace
+
+extern "C" {
+
+int sdrx_wait(sdrx_ctx *c)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    int p = 0;
+    const int rc = wait_frame(c, &p);
+    if (rc)
+        return rc;
     publish_all(c, p);
     return SDRX_OK;
 }
@@ -1224,6 +1442,8 @@ int sdrx_fetch(sdrx_ctx *c)
     HIPCHK(c, hipSetDevice(c->device));
     const int p = (int)((c->frame_no - 1) & 1ull); // the last frame's payloads
     hipStream_t ts = c->opt_pipeline ? c->tail_stream : c->stream;
+    if (int rc = pipeline_flush(c)) // frames still inside the software pipeline run to their end first
+        return rc;
     if (c->pending_fetch)
         HIPCHK(c, hipMemcpyAsync(c->h_pay[p], c->d_pay[p], c->pay_bytes, hipMemcpyDeviceToHost, ts));
     int rc = drain(c);
@@ -1464,3 +1684,5 @@ int sdrx_get_kernel_times(sdrx_ctx *c, double ms[SDRX_NKERNELS], int64_t launche
 }
 
 } // extern "C"
+
+#include "sdrx_group.hip"

@@ -16,10 +16,23 @@ namespace sdrx {
 #define SDRX_PI 3.14159265358979323846264338327950288
 #endif
 
-// Returns false where firfilter::sanity_check_1f (firfilter.cpp:122-134) would throw.
+// firfilter::sanity_check_1f (firfilter.cpp:122-134): the what() text of the std::out_of_range it
+// throws for this specification, or nullptr if it passes.
+inline const char *low_pass_rejection(double fs, double fc, double tw)
+{
+    if (fs <= 0.0)
+        return "firdes check failed: sampling_freq > 0";
+    if (fc <= 0.0 || fc > fs / 2)
+        return "firdes check failed: 0 < fa <= sampling_freq / 2";
+    if (tw <= 0)
+        return "firdes check failed: transition_width > 0";
+    return nullptr;
+}
+
+// Returns false where firfilter::sanity_check_1f would throw.
 inline bool design_low_pass(double gain, double fs, double fc, double tw, std::vector<float> &taps)
 {
-    if (!(fs > 0.0) || !(fc > 0.0) || fc > fs / 2 || !(tw > 0))
+    if (low_pass_rejection(fs, fc, tw) || !(fs > 0.0) || !(tw > 0)) // (the second half also catches NaNs)
         return false;
     int ntaps = (int)(53.0 * fs / (22.0 * tw)); // max_attenuation(HAMMING) = 53, compute_ntaps 108-119
     if ((ntaps & 1) == 0)

@@ -30,7 +30,7 @@ class Receiver:
     """One libsdrx context: a VFO tree on one GPU."""
 
     def __init__(self, device: int = 0, exact: bool = True, keep_prequant: bool = False, segments: int = 0,
-                 dc_blocked_scan: bool = False, pipeline: bool = True):
+                 dc_blocked_scan: bool = False, pipeline: bool = False, fuse: bool = True, frame_pipeline: bool = True):
         self.L = _lib.lib()
         h = C.c_void_p()
         rc = self.L.sdrx_create(C.byref(h), int(device))
@@ -46,6 +46,8 @@ class Receiver:
         self._chk(self.L.sdrx_set_option(self.h, b"segments", int(segments)))
         self._chk(self.L.sdrx_set_option(self.h, b"dc_blocked_scan", int(bool(dc_blocked_scan))))
         self._chk(self.L.sdrx_set_option(self.h, b"pipeline", int(bool(pipeline))))
+        self._chk(self.L.sdrx_set_option(self.h, b"fuse", int(bool(fuse))))
+        self._chk(self.L.sdrx_set_option(self.h, b"frame_pipeline", int(bool(frame_pipeline))))
         self.finalized = False
 
     # -- plumbing -----------------------------------------------------------------
@@ -206,6 +208,107 @@ class Receiver:
         self._chk(self.L.sdrx_get_kernel_times(self.h, ms, n, b))
         return {self.L.sdrx_kernel_name(k).decode(): {"ms": ms[k], "launches": n[k], "alg_bytes": b[k]}
                 for k in range(_lib.NKERNELS) if n[k]}
+
+
+class Group:
+    """One VFO tree on several GPUs from this one process (``sdrx_group_*``): one context per entry of
+    `devices` (a device may be named twice: two shards on one GPU), sub VFOs block-partitioned per
+    main VFO, the raw frame fanned out from the first device by peer-to-peer copies.  Ids are those of
+    the whole tree; `published` holds the last delivered frame's messages in the reference's order."""
+
+    def __init__(self, devices, exact: bool = True, **options):
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self.L.sdrx_group_create(C.byref(h), arr, len(devices))
+        if rc != 0:
+            raise SdrxError(rc, self.L.sdrx_group_last_error(None).decode())
+        self.h = h
+        self.devices = list(devices)
+        self.descs: list[VfoDesc] = []
+        self.published: list[tuple[bytes, int, bytes]] = []
+        self._cb = _lib.PUBLISH_FN(lambda user, topic, rate, buf, length: self.published.append(
+            (C.string_at(topic, 5), int(rate), C.string_at(buf, length))))
+        self._chk(self.L.sdrx_group_set_publish_callback(self.h, self._cb, None))
+        self._chk(self.L.sdrx_group_set_option(self.h, b"exact", int(bool(exact))))
+        for k, v in options.items():
+            self._chk(self.L.sdrx_group_set_option(self.h, k.encode(), int(v)))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SdrxError(rc, self.L.sdrx_group_last_error(self.h).decode())
+
+    @classmethod
+    def from_topology(cls, topo: Topology, devices, **kw) -> "Group":
+        g = cls(devices, **kw)
+        for d in topo.vfos:
+            c = _lib.desc_to_c(d)
+            out = C.c_int(-1)
+            g._chk(g.L.sdrx_group_add_vfo(g.h, C.byref(c), C.byref(out)))
+            g.descs.append(d)
+        g._chk(g.L.sdrx_group_finalize(g.h))
+        return g
+
+    def process(self, iq) -> None:
+        iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
+        self.published.clear()
+        self._chk(self.L.sdrx_group_process(self.h, iq.ctypes.data, iq.size // 2))
+
+    def submit(self, iq) -> None:
+        iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
+        self._chk(self.L.sdrx_group_submit(self.h, iq.ctypes.data, iq.size // 2))
+
+    def submit_u8(self, iq_bytes) -> None:
+        b = np.ascontiguousarray(iq_bytes, dtype=np.uint8).reshape(-1)
+        self._chk(self.L.sdrx_group_submit_u8(self.h, b.ctypes.data, b.size // 2))
+
+    def submit_device(self, dev_ptr: int, n_complex: int, producer_stream: int | None = None) -> None:
+        self._chk(self.L.sdrx_group_submit_device(self.h, C.c_void_p(dev_ptr), int(n_complex), C.c_void_p(producer_stream or 0)))
+
+    def wait(self) -> None:
+        self.published.clear()
+        self._chk(self.L.sdrx_group_wait(self.h))
+
+    def sync(self) -> None:
+        self._chk(self.L.sdrx_group_sync(self.h))
+
+    def in_flight(self) -> int:
+        return int(self.L.sdrx_group_in_flight(self.h))
+
+    def output(self, vid: int) -> np.ndarray:
+        buf, ln, rate = C.c_void_p(), C.c_uint32(), C.c_uint32()
+        self._chk(self.L.sdrx_group_get_output(self.h, vid, C.byref(buf), C.byref(ln), C.byref(rate)))
+        raw = C.string_at(buf.value, ln.value)
+        return np.frombuffer(raw, dtype=np.int16 if self.descs[vid].demod_usb else np.int8).copy()
+
+    def locate(self, vid: int) -> tuple[int, int]:
+        m, l = C.c_int(), C.c_int()
+        self._chk(self.L.sdrx_group_locate(self.h, vid, C.byref(m), C.byref(l)))
+        return m.value, l.value
+
+    def member_stats(self) -> list[dict | None]:
+        out = []
+        for k in range(len(self.devices)):
+            ctx, dev = C.c_void_p(), C.c_int()
+            self._chk(self.L.sdrx_group_member(self.h, k, C.byref(ctx), C.byref(dev)))
+            if not ctx.value:
+                out.append(None)
+                continue
+            s = _lib.StatsC()
+            self.L.sdrx_get_stats(ctx, C.byref(s))
+            out.append({k2: getattr(s, k2) for k2, _ in s._fields_})
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sdrx_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # =============================================================================================

@@ -17,11 +17,30 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 CASES = ["config1", "profile_25e", "config4_12"]
 
 
-def _run(kind, name):
+def _run(kind, name, copies=1, repeat=1):
     want = json.load(open(os.path.join(GOLD, f"dropin_{name}.json")))
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "dropin_run.py"), kind, name, str(want["frames"]),
-                                   want["fft_topic"]], text=True, timeout=600)
-    return [json.loads(l) for l in out.splitlines()], want["lines"]
+                                   want["fft_topic"], str(copies), str(repeat)], text=True, timeout=600)
+    lines = want["lines"]
+    if copies > 1 or repeat > 1:
+        # `copies` receivers fed in turn: per frame the messages (and fftData emissions) of copy 1, then of
+        # copy 2, ...; `repeat` build-run-delete cycles in one process: the whole stream again (zero start state)
+        msgs = [l for l in lines if "topic" in l]
+        ffts = [l for l in lines if "fft" in l]
+        per = len(msgs) // want["frames"]
+        assert per * want["frames"] == len(msgs)
+        one = []
+        for f in range(want["frames"]):
+            one += msgs[f * per:(f + 1) * per] * copies
+        for l in ffts:
+            one += [l] * copies
+        lines = one * repeat
+    return [json.loads(l) for l in out.splitlines()], lines
+
+
+def _probe(kind):
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "dropin_run.py"), "probe", kind], text=True, timeout=120)
+    return json.loads(out.splitlines()[-1])
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -38,6 +57,43 @@ def test_adapter_behind_the_unmodified_header_publishes_the_same_bytes(name):
     lib = os.path.join(ROOT, "oracle", "_ref", "libdropin_sdrx.so")
     assert os.path.exists(lib), "oracle/_ref/libdropin_sdrx.so must travel with the snapshot (make -C host/qt in the build container)"
     got, want = _run("sdrx", name)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g == w
+
+
+def test_reference_copes_with_two_receivers_and_restart():
+    """What the GPU test below expects of the adapter, established on the reference build: two receivers
+    built from one description and fed in turn publish every message twice per frame; a build-run-delete
+    cycle repeated in one process repeats the stream (all state starts from zero)."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdropin_ref.so")):
+        pytest.skip("oracle/_ref/libdropin_ref.so not built (make -C host/qt needs /root/reference)")
+    got, want = _run("ref", "config1", copies=2, repeat=2)
+    assert got == want
+
+
+def test_init_throws_where_the_reference_throws():
+    """vfo::init of the reference throws std::out_of_range from firfilter::sanity_check_1f for a filter
+    bandwidth above half the output rate (vfo.cpp:110-115 -> firfilter.cpp:122-134).  The adapter's init
+    -- validated on the host through sdrx_check_vfo, no GPU involved -- throws the same exception type
+    with the same what() text for the same descriptions, and nothing for the valid ones."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdropin_ref.so")):
+        pytest.skip("oracle/_ref/libdropin_ref.so not built (make -C host/qt needs /root/reference)")
+    ref = _probe("ref")
+    assert ref["ok"][0] == 0 and ref["bw_exactly_half_rate"][0] == 0 and ref["late_ok"][0] == 0
+    assert ref["bw_above_half_rate"] == [1, "firdes check failed: 0 < fa <= sampling_freq / 2"]
+    assert ref["late_bw_too_wide"][0] == 1
+    assert _probe("sdrx") == ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["profile_25e", "config4_12"])
+def test_adapter_two_receivers_and_stop_start(name):
+    """Trees are keyed by their root object, not by a process-wide registry: two receivers built from one
+    description live side by side in one process (each main VFO runs its own context), and the whole
+    build - run - delete cycle (MainWindow's stop / start, vfo.cpp:34-59) is done twice in that process.
+    Every message and fftData emission of both receivers, both cycles, byte-identical to the reference's."""
+    got, want = _run("sdrx", name, copies=2, repeat=2)
     assert len(got) == len(want)
     for g, w in zip(got, want):
         assert g == w

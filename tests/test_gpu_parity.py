@@ -149,12 +149,13 @@ def test_config4_256_vfos_vs_cpu(Receiver):
 
 
 # ------------------------------------------------------------------------------ structure
-def test_time_segmentation_is_invisible(Receiver):
+@pytest.mark.parametrize("fuse", [True, False])
+def test_time_segmentation_is_invisible(Receiver, fuse):
     """Splitting a VFO-frame into time segments (with warm-up chunks) must not change a bit."""
     topo = golden_topology("profile_25e")
     outs = []
     for seg in (1, 3, 7):
-        rx = Receiver.from_topology(topo, exact=True, segments=seg)
+        rx = Receiver.from_topology(topo, exact=True, segments=seg, fuse=fuse)
         frames = []
         for f, iq in _frames(topo, 3, seed=4):
             rx.process(iq)
@@ -168,9 +169,17 @@ def test_time_segmentation_is_invisible(Receiver):
                 assert np.array_equal(bits(a), bits(b))
 
 
-@pytest.mark.parametrize("pipeline", [True, False])
-@pytest.mark.parametrize("key", ["profile_25e", "54w"])
-def test_async_frames_back_to_back(Receiver, key, pipeline):
+LAUNCH_MODES = {  # how a frame's kernels are launched (options of sdrx_set_option); results must not differ by one bit
+    "one-launch, pipelined": dict(fuse=True, frame_pipeline=True),   # default: k_mix_levels, level l of frame k-l in one launch
+    "one-launch per part": dict(fuse=True, frame_pipeline=False),    # k_mix_levels, one level per launch
+    "separate kernels": dict(fuse=False),                            # k_mix_decimate per level
+    "two streams": dict(fuse=False, pipeline=True),                  # ... with the leaf tail on a second stream
+}
+
+
+@pytest.mark.parametrize("mode", sorted(LAUNCH_MODES))
+@pytest.mark.parametrize("key", ["profile_25e", "54w", "compress"])
+def test_async_frames_back_to_back(Receiver, key, mode):
     """sdrx_process_device is asynchronous: 9 frames queued on a caller's stream without any
     synchronisation in between (level 0 of a frame may start while the previous frame's
     demodulation is still running), one sdrx_fetch at the end.  Streams and payloads equal the
@@ -182,7 +191,7 @@ def test_async_frames_back_to_back(Receiver, key, pipeline):
     for iq in frames:
         ob.process_roots(roots, iq)
     st = torch.cuda.Stream()
-    rx = Receiver.from_topology(topo, exact=True, pipeline=pipeline)
+    rx = Receiver.from_topology(topo, exact=True, **LAUNCH_MODES[mode])
     rx.set_stream(st.cuda_stream)
     with torch.cuda.stream(st):
         dev = [torch.from_numpy(iq).cuda(non_blocking=True) for iq in frames]
@@ -308,6 +317,93 @@ def test_vfos_are_independent_and_shardable(Receiver):
     rx.close()
     for _, r in shards:
         r.close()
+
+
+@pytest.mark.parametrize("members", [2, 3])
+@pytest.mark.parametrize("key", ["profile_25e", "config3-64", "54w"])
+def test_group_of_contexts_in_one_process(members, key):
+    """The native multi-device host (sdrx_group_*): one process, one context per device entry -- here
+    2 or 3 shards on the one GPU of the test box, so the fan-out runs as device copies instead of xGMI
+    peer copies -- the tree partitioned in C++ like topology.shard, raw frames fanned out from the
+    first member, payloads published in the reference's order over the WHOLE tree (main order x sub
+    order, sdrj.cpp:288-294 / vfo.cpp:257-263) whichever member computed them.  Every message of every
+    frame equals the oracle's; synchronous and pipelined (submit / wait) interface; byte input."""
+    from sdrreceiver_amd.receiver import Group, SdrxError
+    topo = tp.config3(64) if key == "config3-64" else golden_topology(key)
+    g = Group.from_topology(topo, [0] * members)
+    nodes, roots = ob.build_tree("port", topo)
+    order = topo.leaves_in_publish_order()
+
+    def want():
+        return [(topo.vfos[i].topic.encode()[:5].ljust(5, b"\0"), topo.vfos[i].output_rate,
+                 (nodes[i].usb() if topo.vfos[i].demod_usb else nodes[i].iq()).tobytes()) for i in order
+                if topo.vfos[i].demod_usb or topo.vfos[i].topic]
+
+    # the partition: every leaf on exactly one member, blocks in order, replicated mains on none
+    where = [g.locate(i)[0] for i in range(len(topo.vfos))]
+    assert all(w >= 0 for w in where)
+    for r in topo.roots():
+        ch = topo.children(r)
+        if ch:
+            assert [where[c] for c in ch] == sorted(where[c] for c in ch)
+            assert [where[c] for c in ch] == [next(k for k in range(members) if (len(ch) * k) // members <= q < (len(ch) * (k + 1)) // members)
+                                              for q in range(len(ch))]
+    frames = [iq for _, iq in _frames(topo, 6, seed=12, tones=[(-377000.0, 25.0)])]
+    for f in range(2):  # synchronous
+        g.process(frames[f])
+        ob.process_roots(roots, frames[f])
+        assert g.published == want(), (key, members, f)
+        assert np.array_equal(g.output(order[0]), nodes[order[0]].usb() if topo.vfos[order[0]].demod_usb else nodes[order[0]].iq())
+    wants = []
+    for f in range(2, 6):
+        ob.process_roots(roots, frames[f])
+        wants.append(want())
+    g.submit(frames[2])  # pipelined: submit(f+1); wait() -> f
+    for f in range(3, 6):
+        g.submit(frames[f])
+        assert g.in_flight() == 2
+        if f == 3:
+            with pytest.raises(SdrxError) as e:
+                g.submit(frames[f])
+            assert e.value.code == -2
+        g.wait()
+        assert g.published == wants[f - 3], (key, members, f - 1)
+    g.wait()
+    assert g.published == wants[3]
+    if key != "config3-64":  # dongle bytes: LUT on every member
+        lcg = synth.Lcg(5)
+        b = synth.lcg_frame_u8(topo.frame, lcg)
+        g.submit_u8(b)
+        g.wait()
+        ob.process_roots(roots, ob.u8_to_float(b))
+        assert g.published == want()
+    st = g.member_stats()
+    assert sum(s["n_leaves"] for s in st if s) == len(order)
+    g.close()
+
+
+def test_group_with_more_devices_than_sub_vfos():
+    """More members than sub VFOs: a member may hold one main VFO with a single sub, or nothing at all
+    (even the first one, the ingest device) -- never a main VFO turned IQ-publishing leaf."""
+    from sdrreceiver_amd.receiver import Group
+    topo = tp.profile_25e()
+    g = Group.from_topology(topo, [0] * 16)  # 12 + 15 subs over 16 members: some members hold one main only
+    nodes, roots = ob.build_tree("port", topo)
+    iq = synth.lcg_frame(topo.frame, synth.Lcg(4))
+    g.process(iq)
+    ob.process_roots(roots, iq)
+    order = topo.leaves_in_publish_order()
+    assert [p for _, _, p in g.published] == [nodes[i].usb().tobytes() for i in order]
+    g.close()
+    c1 = tp.config1()  # the single sub lands on member 1: member 0 (the ingest device) holds nothing
+    g = Group.from_topology(c1, [0, 0])
+    assert g.member_stats()[0] is None and g.locate(1) == (1, 1)
+    nodes, roots = ob.build_tree("port", c1)
+    for f, iq in _frames(c1, 3, seed=6):
+        g.process(iq)
+        ob.process_roots(roots, iq)
+        assert g.published == [(b"VFO01", 12000, nodes[1].usb().tobytes())]
+    g.close()
 
 
 def test_full_size_properties_config3(Receiver):
@@ -578,7 +674,7 @@ def test_random_trees_against_the_oracle(Receiver):
         rng = np.random.default_rng(1000 + seed)
         topo = _random_topology(rng)
         try:
-            rx = Receiver.from_topology(topo, exact=True, segments=seed % 5)  # 0 = the library's own choice
+            rx = Receiver.from_topology(topo, exact=True, segments=seed % 5, fuse=seed % 3 != 0)  # segments 0 = the library's own choice
         except SdrxError as e:
             assert "fs >= 1024" in str(e), (seed, str(e))
             continue
@@ -587,6 +683,43 @@ def test_random_trees_against_the_oracle(Receiver):
             rx.process(iq)
             ob.process_roots(roots, iq)
             _check_exact(rx, nodes, topo, ("random", seed, f))
+        rx.close()
+        ran += 1
+    assert ran >= 55, ran
+
+
+@pytest.mark.parametrize("mode", ["one-launch, pipelined", "one-launch per part", "separate kernels"])
+def test_frame_pipeline_on_random_trees(Receiver, mode):
+    """The software pipeline of k_mix_levels (level l of frame k - l in one launch, the leaf tail of the
+    frame that left the last level behind it) on the 60 random trees: 6 frames queued back to back with sdrx_process_device, for odd
+    seeds with an sdrx_sync in the middle (the pipeline drains and fills again); streams and payloads of
+    the last frame -- which depend on every earlier frame through the filter histories -- bit-identical
+    to the oracle's, and a fetch in the middle serves the frame it should."""
+    import torch
+    from sdrreceiver_amd.receiver import SdrxError
+    ran = 0
+    for seed in range(60):
+        rng = np.random.default_rng(1000 + seed)
+        topo = _random_topology(rng)
+        try:
+            rx = Receiver.from_topology(topo, exact=True, segments=seed % 3, **LAUNCH_MODES[mode])
+        except SdrxError as e:
+            assert "fs >= 1024" in str(e), (seed, str(e))
+            continue
+        nodes, roots = ob.build_tree("port", topo)
+        frames = [iq for _, iq in _frames(topo, 6, seed=seed, tones=[(topo.fs / 7.3, 20.0)])]
+        dev = [torch.from_numpy(iq).cuda() for iq in frames]
+        torch.cuda.synchronize()
+        for f, d in enumerate(dev):
+            rx.process_device(d.data_ptr(), topo.frame)
+            ob.process_roots(roots, frames[f])
+            if f == 2 and seed % 2:
+                rx.sync()
+            if f == 3 and seed % 4 == 0:
+                rx.fetch()
+                _check_exact(rx, nodes, topo, ("pipeline-mid", mode, seed))
+        rx.fetch()
+        _check_exact(rx, nodes, topo, ("pipeline", mode, seed))
         rx.close()
         ran += 1
     assert ran >= 55, ran

@@ -168,6 +168,22 @@ def test_cpp_host_end_to_end(u8, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("u8", [False, True])
+def test_cpp_host_on_several_devices(u8, tmp_path):
+    """host/sdrx_host.hpp's sdrj over a device LIST (sdrx_group_*: the native single-process multi-GPU
+    host; here three shards on the one GPU of the test box): the same messages in the same order as the
+    single-device run, and the VFO spectrum tap served from whichever member holds the VFO."""
+    _build()
+    p = tmp_path / "profile.ini"
+    p.write_text(INI_25E_LIKE)
+    for fft, frames in (("VFO19", "3"), ("Main", "9")):
+        args = [DEMO, str(p), "--frames", frames] + (["--u8"] if u8 else []) + ["--fft", fft]
+        one = subprocess.check_output(args, text=True).splitlines()
+        many = subprocess.check_output(args + ["--devices", "0,0,0"], text=True).splitlines()
+        assert len(one) >= 9 and any(l.startswith("fft ") for l in one) and one == many, fft
+
+
+@pytest.mark.gpu
 def test_cpp_host_fft_taps(tmp_path):
     """fftVFOSlot / fftData of vfo (vfo.cpp:290-293,492-509: the selected VFO's
     decimate[decimateCount] after every frame) and of sdrj (sdrj.cpp:84-101,296-303: the raw

@@ -1,4 +1,4 @@
-"""tools/dropin_run.py <ref|sdrx> <topology> <frames> [fft_topic]
+"""tools/dropin_run.py <ref|sdrx> <topology> <frames> [fft_topic] [copies] [repeat]
 
 Runs host/qt/dropin_client.cpp (a client of the reference's unmodified vfo.h public interface) with
 one of the two implementations of `class vfo` behind it -- oracle/_ref/libdropin_ref.so (the
@@ -6,7 +6,9 @@ reference's own sources) or oracle/_ref/libdropin_sdrx.so (host/qt/vfo_adapter.c
 needs the GPU) -- and prints what a ZMQ subscriber received: one JSON line per message
 {"topic": hex of the 5 topic bytes, "rate": u32, "len": payload bytes, "fnv": fnv1a64 of payload},
 then one line per fftData emission {"fft": [frame, topic, count, fnv1a64 hex]}.
-A separate process per run: the reference's bind publisher is a process-wide static."""
+`copies` receivers are built from the same description and fed in turn; the whole build-run-delete
+cycle is done `repeat` times in this process (stop / start), output concatenated.
+A separate process per invocation: the reference's bind publisher is a process-wide static."""
 import ctypes as C
 import json
 import os
@@ -35,9 +37,44 @@ def topology(name):
     raise SystemExit(f"unknown topology {name}")
 
 
+def probe(kind):
+    """tools/dropin_run.py probe <ref|sdrx>: does vfo::init throw, and what, for a few descriptions
+    (firfilter::sanity_check_1f, firfilter.cpp:122-134, reached from vfo.cpp:82-87,110-115)."""
+    C.CDLL("libstdc++.so.6", mode=C.RTLD_GLOBAL)
+    from sdrreceiver_amd import topology as tp
+    from sdrreceiver_amd._lib import desc_to_c
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", f"libdropin_{kind}.so"))
+    base = tp.config1().vfos[1]  # 384 k -> 12 k, filter_bw 4000
+    from dataclasses import replace
+    cases = {
+        "ok": base,
+        "bw_above_half_rate": replace(base, filter_bw=7000),          # 7000 > 12000 / 2
+        "bw_exactly_half_rate": replace(base, filter_bw=6000),        # allowed: fa <= fs / 2
+        "late_ok": replace(base, fs=240000, decimate_count=0, late_decimate=5, filter_bw=10000, samples_per_buffer=60000),
+        "late_bw_too_wide": replace(base, fs=240000, decimate_count=0, late_decimate=5, filter_bw=30000, samples_per_buffer=60000),
+        "main_is_never_filtered": replace(base, demod_usb=False, filter_bw=0),
+    }
+    addr = f"ipc:///tmp/sdrx_dropin_probe_{os.getpid()}".encode()
+    out = {}
+    for name, d in cases.items():
+        what = C.create_string_buffer(256)
+        c = desc_to_c(d)
+        rc = lib.dropin_init_probe(C.byref(c), addr, what, len(what))
+        out[name] = [rc, what.value.decode()]
+    print(json.dumps(out))
+    try:
+        os.unlink(addr.decode()[len("ipc://"):])
+    except OSError:
+        pass
+
+
 def main():
+    if sys.argv[1] == "probe":
+        return probe(sys.argv[2])
     kind, name, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
     fft_topic = sys.argv[4] if len(sys.argv) > 4 else ""
+    copies = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    repeat = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     C.CDLL("libstdc++.so.6", mode=C.RTLD_GLOBAL)  # the system's, before /opt/conda's older one can be picked up
     from sdrreceiver_amd._lib import VfoDescC, desc_to_c
     topo = topology(name)
@@ -48,7 +85,16 @@ def main():
     out = C.create_string_buffer(cap)
     fft = C.create_string_buffer(1 << 16)
     addr = f"ipc:///tmp/sdrx_dropin_{os.getpid()}".encode()
-    n = lib.dropin_run(descs, len(topo.vfos), addr, frames, fft_topic.encode(), out, cap, fft, len(fft))
+    for _ in range(repeat):
+        run_once(lib, descs, len(topo.vfos), addr, frames, fft_topic, out, cap, fft, copies)
+    try:
+        os.unlink(addr.decode()[len("ipc://"):])
+    except OSError:
+        pass
+
+
+def run_once(lib, descs, nv, addr, frames, fft_topic, out, cap, fft, copies):
+    n = lib.dropin_run(descs, nv, addr, frames, fft_topic.encode(), out, cap, fft, len(fft), copies)
     if n < 0:
         raise SystemExit(f"dropin_run failed: {n}")
     buf, pos = out.raw[:n], 0
@@ -67,10 +113,6 @@ def main():
     for line in fft.value.decode().splitlines():
         f, t, cnt, h = line.split()
         print(json.dumps({"fft": [int(f), t, int(cnt), h]}))
-    try:
-        os.unlink(addr.decode()[len("ipc://"):])
-    except OSError:
-        pass
 
 
 if __name__ == "__main__":

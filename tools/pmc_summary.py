@@ -17,7 +17,19 @@ KERNEL_KEYS = {
     "k_mix_decimate<true, 1>": "k_mix_decimate(sub)", "k_mix_decimate<false, 1>": "k_mix_decimate(sub)",
     "k_mix_decimate<true, 0>": "k_mix_decimate(level0)", "k_mix_decimate<false, 0>": "k_mix_decimate(level0)",
     "k_usb_demod": "k_usb_demod", "k_late_decimate": "k_late_decimate", "k_compress": "k_compress",
-    "k_ingest": "k_ingest",
+    "k_ingest": "k_ingest", "k_frame": "k_frame",
+}
+
+# VALU wave-instructions k_mix_decimate issues per 1024-sample chunk of a d = 5 sub VFO, counted in the
+# source (sdrreceiver_amd/csrc/kernels.hip; a packed v_pk_*_f32 on a (re, im) pair counts as ONE):
+INST_MIX_D5 = {
+    "nco_replay": 16 * 7,      # cmul 3 + n*n 1 + (x+y) 1 + (1.95-s) 1 + n*norm 1, per table entry
+    "mix": 16 * 3,             # cmul per sample
+    "stage0_registers": 8 * 11,  # 3 pair sums, 4 products, 3 sums, 0+s -- per output (hb_dot2)
+    "stage1_registers": 4 * 11,
+    "dpp_halo_moves": 2 * 16,  # v_mov_b32_dpp wave_shr:1, two per shifted complex value, 8 values per stage
+    "stages2to4_lds": (2 + 1 + 1) * 11,  # 128 / 64 / 32 outputs per chunk over 64 lanes
+    "addressing_loop_stores": 46,        # the rest of the measured ~414: address arithmetic, selects, loop
 }
 
 
@@ -38,11 +50,27 @@ def main():
             k = key_of(r["Kernel_Name"])
             if k:
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    res = {"source": os.path.relpath(d), "workload": workload, "exact": exact, "kernels": {},
+    sha = "unknown"
+    try:
+        sha = open(os.path.join(d, "build_sha.txt")).read().strip()
+    except OSError:
+        pass
+    # average kernel durations of the kernel-trace pass of the same profile directory
+    avg_us = {}
+    for f in glob.glob(os.path.join(d, "*kernel_stats.csv")):
+        for r in csv.DictReader(open(f)):
+            k = key_of(r["Name"])
+            if k:
+                avg_us[k] = float(r["AverageNs"]) / 1e3
+    res = {"source": os.path.relpath(d), "git_sha": sha, "workload": workload, "exact": exact, "kernels": {},
+           "inst_mix": {"k_mix_decimate, d=5 sub VFO, per 1024-sample chunk (source count, packed = 1)": INST_MIX_D5,
+                        "sum": sum(INST_MIX_D5.values())},
            "note": "per-launch means; hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE correction)"}
     for k, c in agg.items():
         m = {n: sum(v) / len(v) for n, v in c.items()}
         e = {"counters": {n: round(v, 1) for n, v in m.items()}}
+        if k in avg_us:
+            e["avg_us"] = round(avg_us[k], 2)
         if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
             e["hbm_read_bytes_per_launch"] = int(2 * m["FETCH_SIZE"] * 1024)
             e["hbm_write_bytes_per_launch"] = int(m["WRITE_SIZE"] * 1024)
