@@ -389,6 +389,16 @@ def main():
         for _k in range(4):
             rx.process(job.frames_np[0])
         abi["sync_with_python_callbacks_ms"] = round((time.perf_counter() - t1) / 4 * 1e3, 4)
+        # the same two loops from a plain C99 host (host/abi_bench.c, a child process: its own context on
+        # the same GPU), callbacks on -- what the reference's Qt host would see
+        exe = os.path.join(ROOT, "host", "abi_bench")
+        if workload == "config3" and os.path.exists(exe):
+            import subprocess
+            try:
+                r = subprocess.run([exe, "1024", str(n_abi), str(local)], capture_output=True, text=True, timeout=180)
+                abi["c_host"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-300:]}
+            except Exception as e:
+                abi["c_host"] = {"error": f"{type(e).__name__}: {e}"}
 
     weak = None
     if world > 1 and workload == "config5":
@@ -415,10 +425,12 @@ def main():
         dom, dom_ms = None, -1.0
         frame_kernel_ms = 0.0
         for name, r in kt.items():
+            if r["launches"] * 2 < kt_steps:
+                continue  # the one or two single-level launches that fill / drain the frame pipeline
             avg = r["ms"] / r["launches"]
             per_frame = r["ms"] / kt_steps
             frame_kernel_ms += per_frame
-            kernels[name] = {"avg_ms": round(avg, 5), "launches_per_frame": r["launches"] // kt_steps,
+            kernels[name] = {"avg_ms": round(avg, 5), "launches_per_frame": int(round(r["launches"] / kt_steps)),
                              "kernel_bytes_per_launch": r["alg_bytes"] // r["launches"],
                              "GBps": round(r["alg_bytes"] / r["launches"] / (avg * 1e-3) / 1e9, 1)}
             if per_frame > dom_ms:

@@ -132,6 +132,20 @@ def test_c99_program_over_the_abi():
     assert "published VFO01 rate 12000 bytes 6000" in r.stdout
 
 
+@pytest.mark.gpu
+def test_c99_host_pipelined_interface():
+    """host/abi_bench.c: a C99 host drives sdrx_process and the sdrx_submit / sdrx_wait pair on a 64-sub
+    config-3 tree from a pageable buffer; every frame delivers every leaf (66 messages would be wrong: the
+    two main VFOs have children and publish nothing), and the pipelined loop is not slower than the
+    synchronous one."""
+    _build()
+    r = subprocess.run([os.path.join(ROOT, "host", "abi_bench"), "64", "8"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["messages_per_frame"] == 64 and out["payload_bytes_per_frame"] == 32 * 6000 + 32 * 24000
+    assert out["sdrx_submit_wait_ms"] <= out["sdrx_process_ms"] * 1.1, out
+
+
 def _fnv1a(b: bytes) -> int:
     h = 1469598103934665603
     for x in b:
