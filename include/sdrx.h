@@ -236,7 +236,7 @@ int sdrx_get_stats(sdrx_ctx *ctx, sdrx_stats *out);
  * kernel launch with events (small overhead: use for profiling runs, not for throughput runs).
  * sdrx_get_kernel_times: accumulated milliseconds and launch counts since enabling, for
  * kernel kinds 0..SDRX_NKERNELS-1 (names from sdrx_kernel_name). */
-#define SDRX_NKERNELS 7
+#define SDRX_NKERNELS 8
 int sdrx_enable_kernel_timing(sdrx_ctx *ctx, int enable);
 int sdrx_get_kernel_times(sdrx_ctx *ctx, double ms[SDRX_NKERNELS], int64_t launches[SDRX_NKERNELS],
                           int64_t alg_bytes[SDRX_NKERNELS]);

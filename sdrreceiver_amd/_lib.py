@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDRX_LIB") or os.path.join(_HERE, "libsdrx.so")  # SDRX_LIB: A/B builds of the SAME HIP library
 CSRC = os.path.join(_HERE, "csrc")
 
-NKERNELS = 7
+NKERNELS = 8
 
 
 class VfoDescC(C.Structure):

@@ -1023,6 +1023,7 @@ __device__ __forceinline__ void demod_block(const K2Vfo *__restrict__ vfos, cons
         int H, n, nlpf, tile;
     } D = {ldc(&Dp->hnz), ldc(&Dp->lpf_pad), ldc(&Dp->pay[par]), ldc(&Dp->prequant), ldc(&Dp->gain),
            ldc(&Dp->H),   ldc(&Dp->n),       ldc(&Dp->nlpf),     ldc(&Dp->tile)};
+    float *usb_out = ldc(&Dp->usb_out[par]); // non-null: a long low-pass follows in k_lpf_long
     const float2 *sbase = ldc(&Dp->s[par]);
     float2 *snext = ldc(&Dp->s_next[par]);
     const int m0 = blk * D.tile;
@@ -1141,6 +1142,11 @@ __device__ __forceinline__ void demod_block(const K2Vfo *__restrict__ vfos, cons
         for (int rr = 0; rr < 4; ++rr)
             u4[rr] = sU[soff + j0 + rr];
     }
+    if (usb_out) { // hand the unfiltered usb values on (k_lpf_long quantises)
+        for (int rr = 0; rr < 4 && m + rr < D.n; ++rr)
+            *(SDRX_AS1 float *)(usb_out + m + rr) = u4[rr];
+        return;
+    }
     short o4[4];
     float pq[4];
 #pragma unroll
@@ -1199,6 +1205,56 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_levels(const K1Vf
     const int lv = ldc(item_level + it);
     mix_item<EXACT>(k1, K1Work{ldc(&items[it].vfo), ldc(&items[it].s_begin), ldc(&items[it].s_first_out), ldc(&items[it].s_end)},
                     A.frame_level[lv], A.raw, A.raw_mode, lv == 0, smem, (int)threadIdx.x);
+}
+
+// An audio low-pass of more than kMaxFir taps (the reference accepts any filter_bandwidth: 500 Hz at
+// 48 kS/s is 925 taps, firfilter.cpp:108-119): usb'[m] = sum_{i<N} hu[i] usb[m-N+i], newest sample
+// excluded (FIR::FIRUpdateAndProcess, dsp.cpp:59-71), one accumulator per output in tap order, then the
+// same quantisation as k_usb_demod.  256 outputs per block; the block's window of N + 256 usb values sits
+// in LDS, the taps are wave-uniform scalar loads.  A rare configuration: correctness first.
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k_lpf_long(const K4Vfo *__restrict__ vfos, const BlockWork *__restrict__ work, unsigned long long frame_no)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *sw = reinterpret_cast<float *>(smem);
+    const K4Vfo *Dp = vfos + ldc(&work[blockIdx.x].vfo);
+    const int blk = ldc(&work[blockIdx.x].blk);
+    const int par = (int)(frame_no & 1ull);
+    const int tid = threadIdx.x;
+    const float *taps = ldc(&Dp->taps);
+    const int Hu = ldc(&Dp->Hu), n = ldc(&Dp->n), N = ldc(&Dp->nlpf);
+    const float gain = ldc(&Dp->gain);
+    const float *ubase = ldc(&Dp->u[par]);
+    float *unext = ldc(&Dp->u_next[par]);
+    short *pay = ldc(&Dp->pay[par]);
+    float *prequant = ldc(&Dp->prequant);
+    if (blk == 0) // history for the next frame: the last Hu entries of [hist | data]
+        for (int j = tid; j < Hu; j += 256)
+            *(SDRX_AS1 float *)(unext + j) = gld(ubase + n + j);
+    const float *u = ubase + Hu; // sample 0 of this frame
+    const int m0 = blk * 256;
+    for (int t = tid; t < N + 256; t += 256) { // window: usb[m0 - N .. m0 + 255]
+        const int idx = m0 - N + t;
+        sw[t] = idx < n ? gld(u + idx) : 0.f;
+    }
+    __syncthreads();
+    const int m = m0 + tid;
+    if (m >= n)
+        return;
+    const float *w = sw + tid; // w[i] = usb[m - N + i]
+    float acc = 0.f;
+    for (int i = 0; i < N; ++i) {
+        const float h = ldc(taps + i);
+        if (EXACT)
+            acc = acc + h * w[i];
+        else
+            acc = fmaf(h, w[i], acc);
+    }
+    const float scaled = acc * gain;
+    const double pre = (double)scaled * 32768.0;
+    *(SDRX_AS1 short *)(pay + m) = to_short(pre);
+    if (prequant)
+        *(SDRX_AS1 float *)(prequant + m) = (float)pre;
 }
 
 // vfo::compress (vfo.cpp:389-424): cstyle 1 packs the high nibbles of (re/scalecomp)*128 and

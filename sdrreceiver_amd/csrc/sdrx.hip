@@ -37,9 +37,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Kind { KIND_MIX_ROOT = 0, KIND_MIX_SUB = 1, KIND_LATE_DEC = 2, KIND_DEMOD = 3, KIND_COMPRESS = 4, KIND_INGEST = 5, KIND_LEVELS = 6 };
+enum Kind { KIND_MIX_ROOT = 0, KIND_MIX_SUB = 1, KIND_LATE_DEC = 2, KIND_DEMOD = 3, KIND_COMPRESS = 4, KIND_INGEST = 5, KIND_LEVELS = 6, KIND_LPF_LONG = 7 };
 const char *kKindNames[SDRX_NKERNELS] = {"k_mix_decimate(level0)", "k_mix_decimate(sub)", "k_late_decimate", "k_usb_demod",
-                                         "k_compress",             "k_ingest",            "k_mix_levels"};
+                                         "k_compress",             "k_ingest",            "k_mix_levels",    "k_lpf_long"};
 
 struct Node {
     sdrx_vfo_desc d;
@@ -53,6 +53,9 @@ struct Node {
     std::vector<float> lpf, dec, hilbert;
     std::vector<float> lpf_pad, hnz; // device forms: zero-padded low-pass, compacted Hilbert
     int demod_tile = 1024;           // outputs per k_usb_demod block
+    bool long_lpf = false;           // audio low-pass of more than kMaxFir taps: applied by k_lpf_long
+    int Hu = 0;                      // its history length (usb floats of the previous frame)
+    size_t off_u[2] = {0, 0};        // its input: [hist Hu | data n_out] usb floats per frame parity
     // device placement (byte offsets into the arena)
     size_t off_cp = 0, off_hb[2] = {0, 0}, off_stream[2] = {0, 0}, off_z[2] = {0, 0}, off_preq = 0;
     size_t off_lpf = 0, off_dec = 0, off_hilbert = 0, off_hnz = 0;
@@ -119,7 +122,7 @@ struct sdrx_ctx {
     // `copy_stream` for frames that came in through sdrx_submit*.  Cross-stream order is by the
     // per-parity events below (measured on this runtime, tools/event_probe.hip: a record costs its
     // stream ~3-5 us, a wait on an event that completed long ago ~2.5 us, a tight hop ~11 us).
-    hipStream_t own_stream = nullptr, stream = nullptr, tail_stream = nullptr, copy_stream = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr, tail_stream = nullptr, copy_stream = nullptr, copy_stream2 = nullptr;
     hipEvent_t ev_levels[2] = {nullptr, nullptr}; // levels of frame f done (recorded on `stream`)
     hipEvent_t ev_tail[2] = {nullptr, nullptr};   // tail of frame f done (recorded on the tail's stream)
     hipEvent_t ev_copied[2] = {nullptr, nullptr}; // payloads of frame f are in h_pay[f & 1]
@@ -351,9 +354,10 @@ int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode, bool egress)
         c->tail_recorded[p] = pipe;
     }
     if (egress) {
-        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_tail[p], 0));
-        HIPCHK(c, hipMemcpyAsync(c->h_pay[p], c->d_pay[p], c->pay_bytes, hipMemcpyDeviceToHost, c->copy_stream));
-        HIPCHK(c, hipEventRecord(c->ev_copied[p], c->copy_stream));
+        hipStream_t cs = (p && c->copy_stream2) ? c->copy_stream2 : c->copy_stream;
+        HIPCHK(c, hipStreamWaitEvent(cs, c->ev_tail[p], 0));
+        HIPCHK(c, hipMemcpyAsync(c->h_pay[p], c->d_pay[p], c->pay_bytes, hipMemcpyDeviceToHost, cs));
+        HIPCHK(c, hipEventRecord(c->ev_copied[p], cs));
         c->in_flight++;
     }
     c->frame_no++;
@@ -390,6 +394,12 @@ void launch_block_kernel(sdrx_ctx *c, const LaunchB &L, hipStream_t ts, unsigned
             hipLaunchKernelGGL(k_usb_demod<true>, grid, dim3(256), 0, ts, k2, w, frame);
         else
             hipLaunchKernelGGL(k_usb_demod<false>, grid, dim3(256), 0, ts, k2, w, frame);
+    } else if (L.kind == KIND_LPF_LONG) {
+        const K4Vfo *k4 = reinterpret_cast<const K4Vfo *>(c->arena + L.off_desc);
+        if (exact)
+            hipLaunchKernelGGL(k_lpf_long<true>, grid, dim3(256), L.lds_bytes, ts, k4, w, frame);
+        else
+            hipLaunchKernelGGL(k_lpf_long<false>, grid, dim3(256), L.lds_bytes, ts, k4, w, frame);
     } else {
         hipLaunchKernelGGL(k_compress, grid, dim3(256), 0, ts, reinterpret_cast<const K3Vfo *>(c->arena + L.off_desc), w, frame);
     }
@@ -465,6 +475,8 @@ int drain(sdrx_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->tail_stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    if (c->copy_stream2)
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream2));
     drain_events(c);
     return SDRX_OK;
 }
@@ -567,6 +579,11 @@ int sdrx_create(sdrx_ctx **out, int device)
     c->stream = c->own_stream;
     bool ok = hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    // odd frames' payloads leave on a copy stream of their own: the next copy's set-up then overlaps the
+    // current copy's tail (measured through the ABI on config 3: 0.296 vs 0.306 ms per frame;
+    // SDRX_TWO_COPY_STREAMS=0 for A/B runs)
+    if (ok && !(getenv("SDRX_TWO_COPY_STREAMS") && atoi(getenv("SDRX_TWO_COPY_STREAMS")) == 0))
+        ok = hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking) == hipSuccess;
     for (int p = 0; p < 2 && ok; ++p)
         ok = hipEventCreateWithFlags(&c->ev_levels[p], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_tail[p], hipEventDisableTiming) == hipSuccess &&
@@ -590,6 +607,8 @@ int sdrx_destroy(sdrx_ctx *c)
         (void)hipStreamSynchronize(c->tail_stream);
     if (c->copy_stream)
         (void)hipStreamSynchronize(c->copy_stream);
+    if (c->copy_stream2)
+        (void)hipStreamSynchronize(c->copy_stream2);
     drain_events(c);
     for (hipEvent_t e : c->event_pool)
         (void)hipEventDestroy(e);
@@ -598,7 +617,7 @@ int sdrx_destroy(sdrx_ctx *c)
             if (e)
                 (void)hipEventDestroy(e);
     free_device_state(c);
-    for (hipStream_t st : {c->own_stream, c->tail_stream, c->copy_stream})
+    for (hipStream_t st : {c->own_stream, c->tail_stream, c->copy_stream, c->copy_stream2})
         if (st)
             (void)hipStreamDestroy(st);
     delete c;
@@ -769,8 +788,9 @@ static int finalize_impl(sdrx_ctx *c)
             if (!design_low_pass(2, (double)target, (double)d.filter_bw_hz, (double)d.filter_bw_hz / 4, n.lpf))
                 return fail(c, SDRX_EFILTER, "vfo %d: filter_bw %d Hz rejected at %d S/s (firfilter.cpp:122-134)", i, d.filter_bw_hz,
                             target);
-            if ((int)n.lpf.size() > kMaxFir)
-                return fail(c, SDRX_EUNSUPPORTED, "vfo %d: %zu-tap audio filter exceeds %d", i, n.lpf.size(), kMaxFir);
+            if ((int)n.lpf.size() > kMaxFirLong)
+                return fail(c, SDRX_EUNSUPPORTED, "vfo %d: %zu-tap audio filter exceeds %d", i, n.lpf.size(), kMaxFirLong);
+            n.long_lpf = (int)n.lpf.size() > kMaxFir;
         }
         if (d.demod_usb) {
             design_hilbert(kHilbert, n.n_out, n.hilbert); // vfo.cpp:137: "Fs" = samplesOut
@@ -781,7 +801,7 @@ static int finalize_impl(sdrx_ctx *c)
                 else if (n.hilbert[(size_t)t] != 0.0f)
                     return fail(c, SDRX_EUNSUPPORTED, "vfo %d: even Hilbert tap %d is not zero", i, t);
             }
-            if (!n.lpf.empty()) {
+            if (!n.lpf.empty() && !n.long_lpf) {
                 n.lpf_pad.assign(n.lpf.size() + 3 + 12, 0.0f);
                 std::copy(n.lpf.begin(), n.lpf.end(), n.lpf_pad.begin() + 3);
             }
@@ -831,7 +851,7 @@ static int finalize_impl(sdrx_ctx *c)
             n.off_hb[p] = plan.take(sizeof(float2) * (size_t)std::max(1, d.decimate_count * kHbHist));
         n.H = n.Hx = 0;
         if (n.leaf && d.demod_usb) {
-            const int Hdemod = (int)align_up((size_t)(n.lpf.size() + 1 + kHilbert - 1), 4);
+            const int Hdemod = (int)align_up((size_t)((n.long_lpf ? 0 : n.lpf.size()) + 1 + kHilbert - 1), 4);
             if (late) {
                 n.Hx = (int)align_up(n.dec.size(), 4);
                 n.H = Hdemod;
@@ -846,6 +866,12 @@ static int finalize_impl(sdrx_ctx *c)
                 n.off_z[p] = plan.take(sizeof(float2) * (size_t)(n.H + n.n_out));
         if (!n.lpf_pad.empty())
             n.off_lpf = place_taps(n.lpf_pad);
+        if (n.long_lpf) {
+            n.off_lpf = place_taps(n.lpf);
+            n.Hu = (int)align_up(n.lpf.size(), 4);
+            for (int p = 0; p < 2; ++p)
+                n.off_u[p] = plan.take(sizeof(float) * (size_t)(n.Hu + n.n_out));
+        }
         if (!n.hnz.empty())
             n.off_hnz = place_taps(n.hnz);
         if (!n.dec.empty())
@@ -1012,7 +1038,7 @@ static int finalize_impl(sdrx_ctx *c)
                 // a block computes E = nlpf (rounded up to even) extra usb values as history for its low-pass:
                 // its tile is shortened by E so that usb stays ONE pass of <= 1024 values (a second pass would
                 // keep two of the four waves busy for a whole Hilbert loop on ~50 values)
-                const int nl = (int)n.lpf.size();
+                const int nl = n.long_lpf ? 0 : (int)n.lpf.size();
                 n.demod_tile = (nl > 0 && !getenv("SDRX_DEMOD_FULL_TILE")) ? ((kDemodTile - (nl + (nl & 1))) & ~3) : kDemodTile;
             }
             for (int b = 0; b < (n.n_out + n.demod_tile - 1) / n.demod_tile; ++b)
@@ -1042,7 +1068,7 @@ static int finalize_impl(sdrx_ctx *c)
         auto cost = [&](const BlockWork &b) {
             const Node &n = c->nodes[(size_t)n2[(size_t)b.vfo]];
             const int outs = std::min(n.demod_tile, n.n_out - b.blk * n.demod_tile);
-            return (long long)outs * (kHilbertNz + (long long)n.lpf.size());
+            return (long long)outs * (kHilbertNz + (long long)(n.long_lpf ? 0 : n.lpf.size()));
         };
         std::stable_sort(w2.begin(), w2.end(), [&](const BlockWork &a, const BlockWork &b) { return cost(a) > cost(b); });
     }
@@ -1050,6 +1076,26 @@ static int finalize_impl(sdrx_ctx *c)
         o2 = plan.take(sizeof(K2Vfo) * d2.size());
         ow2 = plan.take(sizeof(BlockWork) * w2.size());
         c->lb.push_back({KIND_DEMOD, (int)w2.size(), o2, ow2, 0, b2});
+    }
+    std::vector<K4Vfo> d4;
+    std::vector<BlockWork> w4;
+    std::vector<int> n4;
+    int lds4 = 0;
+    for (int i = 0; i < N; ++i) {
+        const Node &n = c->nodes[(size_t)i];
+        if (n.leaf && n.d.demod_usb && n.long_lpf) {
+            for (int b = 0; b < (n.n_out + 255) / 256; ++b)
+                w4.push_back({(int)d4.size(), b});
+            n4.push_back(i);
+            d4.push_back(K4Vfo{});
+            lds4 = std::max(lds4, (int)sizeof(float) * ((int)n.lpf.size() + 256));
+        }
+    }
+    size_t o4 = 0, ow4 = 0;
+    if (!d4.empty()) {
+        o4 = plan.take(sizeof(K4Vfo) * d4.size());
+        ow4 = plan.take(sizeof(BlockWork) * w4.size());
+        c->lb.push_back({KIND_LPF_LONG, (int)w4.size(), o4, ow4, lds4, 0});
     }
     if (!d3.empty()) {
         o3 = plan.take(sizeof(K3Vfo) * d3.size());
@@ -1160,15 +1206,32 @@ static int finalize_impl(sdrx_ctx *c)
             k.s_next[p] = reinterpret_cast<float2 *>(P(late ? n.off_z[p ^ 1] : n.off_stream[p ^ 1]));
         }
         k.hnz = reinterpret_cast<const float *>(P(n.off_hnz));
-        k.lpf_pad = n.lpf.empty() ? nullptr : reinterpret_cast<const float *>(P(n.off_lpf));
+        k.lpf_pad = (n.lpf.empty() || n.long_lpf) ? nullptr : reinterpret_cast<const float *>(P(n.off_lpf));
+        for (int p = 0; p < 2; ++p)
+            k.usb_out[p] = n.long_lpf ? reinterpret_cast<float *>(P(n.off_u[p])) + n.Hu : nullptr;
         for (int p = 0; p < 2; ++p)
             k.pay[p] = reinterpret_cast<short *>(c->d_pay[p] + n.pay_off);
         k.prequant = (c->opt_prequant) ? reinterpret_cast<float *>(P(n.off_preq)) : nullptr;
         k.gain = n.d.gain;
         k.H = late ? n.H : n.Hx;
         k.n = n.n_out;
-        k.nlpf = (int)n.lpf.size();
+        k.nlpf = n.long_lpf ? 0 : (int)n.lpf.size();
         k.tile = n.demod_tile;
+    }
+    for (size_t q = 0; q < d4.size(); ++q) {
+        Node &n = c->nodes[(size_t)n4[q]];
+        K4Vfo &k = d4[q];
+        for (int p = 0; p < 2; ++p) {
+            k.u[p] = reinterpret_cast<const float *>(P(n.off_u[p]));
+            k.u_next[p] = reinterpret_cast<float *>(P(n.off_u[p ^ 1]));
+            k.pay[p] = reinterpret_cast<short *>(c->d_pay[p] + n.pay_off);
+        }
+        k.taps = reinterpret_cast<const float *>(P(n.off_lpf));
+        k.prequant = (c->opt_prequant) ? reinterpret_cast<float *>(P(n.off_preq)) : nullptr;
+        k.gain = n.d.gain;
+        k.Hu = n.Hu;
+        k.n = n.n_out;
+        k.nlpf = (int)n.lpf.size();
     }
     for (size_t q = 0; q < d3.size(); ++q) {
         Node &n = c->nodes[(size_t)n3[q]];
@@ -1192,6 +1255,8 @@ static int finalize_impl(sdrx_ctx *c)
     HIPCHK(c, up(ow2a, w2a.data(), sizeof(BlockWork) * w2a.size()));
     HIPCHK(c, up(o2, d2.data(), sizeof(K2Vfo) * d2.size()));
     HIPCHK(c, up(ow2, w2.data(), sizeof(BlockWork) * w2.size()));
+    HIPCHK(c, up(o4, d4.data(), sizeof(K4Vfo) * d4.size()));
+    HIPCHK(c, up(ow4, w4.data(), sizeof(BlockWork) * w4.size()));
     HIPCHK(c, up(o3, d3.data(), sizeof(K3Vfo) * d3.size()));
     HIPCHK(c, up(ow3, w3.data(), sizeof(BlockWork) * w3.size()));
     if (c->fp.usable) {
@@ -1595,7 +1660,7 @@ int sdrx_get_taps(sdrx_ctx *c, int id, int which, float *out, int max, int *n_re
     if (!t)
         return fail(c, SDRX_EINVAL, "which must be 0, 1 or 2");
     // read back what the kernels actually use (device copy), not the host vector
-    const size_t off = which == 0 ? n.off_lpf + 3 * sizeof(float) : which == 1 ? n.off_dec : n.off_hilbert;
+    const size_t off = which == 0 ? n.off_lpf + (n.long_lpf ? 0 : 3 * sizeof(float)) : which == 1 ? n.off_dec : n.off_hilbert;
     const int cnt = std::min(max, (int)t->size());
     HIPCHK(c, hipSetDevice(c->device));
     if (out && cnt > 0)

@@ -14,7 +14,8 @@ constexpr int kMaxLevels = 4;       // tree depth up to which the one-launch fra
 constexpr int kHilbert = 125;       // vfo.cpp:137
 constexpr int kHilbertNz = 62;      // non-zero Hilbert taps (odd indices 1..123)
 constexpr int kDelay = 62;          // vfo.cpp:136
-constexpr int kMaxFir = 256;        // longest low-pass the demod kernels stage in LDS
+constexpr int kMaxFir = 256;        // longest low-pass k_usb_demod applies itself (staged in LDS); longer ones: k_lpf_long
+constexpr int kMaxFirLong = 8192;   // longest low-pass at all (window + block in LDS: 33 KB)
 // where the parent-less VFOs of a launch read the raw frame from
 constexpr int kRawTiled = 0;        // the context's tile-layout copy (an ingest kernel wrote it)
 constexpr int kRawF32 = 1;          // the caller's cf32 frame, natural order
@@ -71,6 +72,8 @@ struct K2Vfo {
     int H, n, nlpf;
     int tile;               // outputs per block: 1024, or 1024 - E with the low-pass (E = nlpf rounded up to even)
     int pad_;
+    float *usb_out[2];      // a low-pass longer than kMaxFir: the unfiltered usb floats go here per frame parity
+                            //   (behind that stream's history) and k_lpf_long does the rest; else null
 };
 static_assert(sizeof(K2Vfo) % 8 == 0, "K2Vfo array stride");
 
@@ -80,6 +83,17 @@ struct K3Vfo {
     signed char *pay[2];    // per frame parity
     int n, cstyle, scalecomp;
     int pad_;
+};
+
+// ---- audio low-pass of more than kMaxFir taps (FIR::FIRUpdateAndProcess, dsp.cpp:59-71) + int16 --------
+struct K4Vfo {
+    const float *u[2];      // [hist Hu | data n] usb floats per frame parity
+    float *u_next[2];       // the other parity's buffer (history for the next frame)
+    const float *taps;      // nlpf taps
+    short *pay[2];
+    float *prequant;
+    float gain;
+    int Hu, n, nlpf;
 };
 
 struct NcoInit {

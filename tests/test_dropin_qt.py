@@ -17,10 +17,11 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 CASES = ["config1", "profile_25e", "config4_12"]
 
 
-def _run(kind, name, copies=1, repeat=1):
+def _run(kind, name, copies=1, repeat=1, env=None):
     want = json.load(open(os.path.join(GOLD, f"dropin_{name}.json")))
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "dropin_run.py"), kind, name, str(want["frames"]),
-                                   want["fft_topic"], str(copies), str(repeat)], text=True, timeout=600)
+                                   want["fft_topic"], str(copies), str(repeat)], text=True, timeout=600,
+                                  env=dict(os.environ, **(env or {})))
     lines = want["lines"]
     if copies > 1 or repeat > 1:
         # `copies` receivers fed in turn: per frame the messages (and fftData emissions) of copy 1, then of
@@ -94,6 +95,17 @@ def test_adapter_two_receivers_and_stop_start(name):
     build - run - delete cycle (MainWindow's stop / start, vfo.cpp:34-59) is done twice in that process.
     Every message and fftData emission of both receivers, both cycles, byte-identical to the reference's."""
     got, want = _run("sdrx", name, copies=2, repeat=2)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g == w
+
+
+@pytest.mark.gpu
+def test_adapter_over_a_device_list():
+    """SDRX_DEVICES=0,0,0: behind the unmodified vfo.h every tree is sharded over a device list
+    (sdrx_group_*; three shards on the one GPU of the test box) -- the subscriber still receives the
+    reference's bytes in the reference's order, and fftData comes from whichever shard holds the VFO."""
+    got, want = _run("sdrx", "profile_25e", env={"SDRX_DEVICES": "0,0,0"})
     assert len(got) == len(want)
     for g, w in zip(got, want):
         assert g == w

@@ -765,6 +765,54 @@ def test_longest_audio_filters(Receiver):
     rx.close()
 
 
+@pytest.mark.parametrize("fuse", [True, False])
+def test_audio_filters_longer_than_256_taps(Receiver, fuse):
+    """The reference accepts any filter_bandwidth (firfilter.cpp:108-119: ntaps = 53 fs / (22 bw/4)):
+    500 Hz at 48 kS/s is 925 taps.  Filters above the 256 taps k_usb_demod applies itself go through
+    k_lpf_long: 309, 463 and 925 taps at 48 kS/s, 771 taps at 12 kS/s, ~3 300 taps at 12 kS/s (longer than
+    the 3 000 outputs of a frame: the history spans two frames), and ~440 taps behind the /6 late
+    decimation -- all bit-identical to the oracle over 6 frames, queued frames included."""
+    import torch
+    t = tp.Topology(fs=1536000, frame=384000, name="longlpf")
+    t.vfos.append(tp.VfoDesc(parent=-1, fs=1536000, decimate_count=3, mixer_freq=-496000.0, demod_usb=False, cstyle=1,
+                             samples_per_buffer=384000))
+    for k, bw in enumerate([1500, 1000, 500, 10000]):
+        t.vfos.append(tp.VfoDesc(topic=f"W{k}", parent=0, fs=192000, decimate_count=2, mixer_freq=float(-41300 + 7000 * k),
+                                 filter_bw=bw, gain=tp._g(0.05), cstyle=1, samples_per_buffer=48000))
+    t.vfos.append(tp.VfoDesc(parent=-1, fs=1536000, decimate_count=2, mixer_freq=484000.0, demod_usb=False, cstyle=1,
+                             samples_per_buffer=384000))
+    for k, bw in enumerate([150, 35]):
+        t.vfos.append(tp.VfoDesc(topic=f"N{k}", parent=5, fs=384000, decimate_count=5, mixer_freq=float(110854 - 9000 * k),
+                                 filter_bw=bw, gain=tp._g(0.05), cstyle=1, samples_per_buffer=96000))
+    t.vfos.append(tp.VfoDesc(parent=-1, fs=1536000, decimate_count=0, mixer_freq=100000.0, demod_usb=False, cstyle=1,
+                             samples_per_buffer=384000))
+    t.vfos.append(tp.VfoDesc(topic="L6", parent=len(t.vfos) - 1, fs=1536000, decimate_count=3, mixer_freq=-30000.0, late_decimate=6,
+                             filter_bw=700, gain=tp._g(0.04), cstyle=1, samples_per_buffer=384000))
+    rx = Receiver.from_topology(t, exact=True, fuse=fuse, keep_prequant=True)
+    nodes, roots = ob.build_tree("port", t)
+    usb = [i for i, v in enumerate(t.vfos) if v.demod_usb]
+    lens = [len(rx.taps(i, "fir_usb")) for i in usb]
+    assert lens[:5] == [309, 463, 925, 47, 771] and lens[5] > 3000 and lens[6] > 256, lens
+    assert lens == [len(nodes[i].taps("fir_usb")) for i in usb]
+    for i in usb:
+        assert np.array_equal(bits(rx.taps(i, "fir_usb")), bits(nodes[i].taps("fir_usb"))), i
+    frames = [iq for _, iq in _frames(t, 6, seed=19, tones=[(-496000.0 - 40000.0, 30.0), (484000.0 + 110000.0, 20.0)])]
+    for f in range(3):
+        rx.process(frames[f])
+        ob.process_roots(roots, frames[f])
+        _check_exact(rx, nodes, t, ("longlpf", f))
+        for i in usb:  # exact: float * 2^15
+            assert np.array_equal(rx.prequant(i).astype(np.float64), nodes[i].usb_prequant()), (f, i)
+    dev = [torch.from_numpy(iq).cuda() for iq in frames[3:]]
+    torch.cuda.synchronize()
+    for f, d in enumerate(dev):
+        rx.process_device(d.data_ptr(), t.frame)
+        ob.process_roots(roots, frames[3 + f])
+    rx.fetch()
+    _check_exact(rx, nodes, t, ("longlpf", "queued"))
+    rx.close()
+
+
 def test_contexts_do_not_leak_device_memory(Receiver):
     """30 receivers created, run for a frame and destroyed (mainwindow's stop/start cycle): device
     memory in use returns to where it was (hipFree of every arena, staging buffer, stream, event)."""
