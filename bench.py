@@ -2,7 +2,7 @@
 """bench.py -- throughput of the per-VFO IQ chain on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R]
-                    [--workload config3|flat|config2|config4|config5|10k|64k|256k]
+                    [--workload config3|flat|config2|config4|config5|10k|64k|256k|512k]
                     [--fast] [--no-cpu] [--no-abi] [--configs1] [--batch B]
 
 A "step" is one pass of the hot path over one raw IQ frame (250 ms of signal: 384 000 cf32 at
@@ -58,6 +58,10 @@ def make_topology(name, world):
                                    "(strong scaling), raw frames broadcast from rank 0")
     if name == "256k":
         return tp.config3(262144 * world), "memory-scale check: 262 144 sub VFOs per GPU under the 2 sdr_25E mains (~70 GB of HBM)"
+    if name == "512k":
+        return tp.config3(524288 * world), "memory-scale check: 524 288 sub VFOs per GPU under the 2 sdr_25E mains (~140 GB of HBM)"
+    if name == "768k":
+        return tp.config3(786432 * world), "memory-scale check: 786 432 sub VFOs per GPU under the 2 sdr_25E mains (~220 GB of HBM)"
     if name == "64k":
         return tp.config3(65536 * world), "BASELINE config 5's tree on ONE GPU: 65 536 sub VFOs under the 2 sdr_25E mains"
     raise SystemExit(f"unknown workload {name}")

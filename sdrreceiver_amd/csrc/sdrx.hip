@@ -756,6 +756,12 @@ static int finalize_impl(sdrx_ctx *c)
         Node &n = c->nodes[(size_t)i];
         const sdrx_vfo_desc &d = n.d;
         n.leaf = n.children.empty();
+        {
+            char why[200];
+            const int rc = sdrx_check_vfo(&d, why, sizeof why); // what a binding may already have asked at init() time
+            if (rc != SDRX_OK)
+                return fail(c, rc, "vfo %d: %s", i, why);
+        }
         if (d.fs % kRun || d.samples_per_buffer % kRun || d.fs < kChunk)
             return fail(c, SDRX_EUNSUPPORTED, "vfo %d: fs (%d) and samples_per_buffer (%d) must be multiples of 16 and fs >= 1024", i,
                         d.fs, d.samples_per_buffer);

@@ -33,6 +33,7 @@ struct sdrx_group {
     sdrx_publish_fn cb = nullptr;
     void *cb_user = nullptr;
     bool finalized = false;
+    bool broken = false; // a launch or wait failed on one member after others had gone ahead: only destroy is left
     int root_frame = 0;
     int in_flight = 0;
     unsigned long long frame_no = 0;
@@ -93,8 +94,10 @@ int group_enqueue(sdrx_group *g, const void *src, size_t bytes, int raw_mode, bo
         }
         M.c->last_raw = -1;
         const int rc = M.c->opt_exact ? enqueue_frame<true>(M.c, raw, raw_mode, egress) : enqueue_frame<false>(M.c, raw, raw_mode, egress);
-        if (rc)
+        if (rc) {
+            g->broken = true; // earlier members already run this frame
             return member_fail(g, (int)k, rc);
+        }
     }
     g->frame_no++;
     if (egress)
@@ -110,6 +113,8 @@ int group_check(sdrx_group *g, const char *what, const void *ptr, int n_complex,
         return gfail(g, SDRX_EINVAL, "%s: null frame pointer", what);
     if (!g->finalized)
         return gfail(g, SDRX_ESTATE, "%s before sdrx_group_finalize", what);
+    if (g->broken)
+        return gfail(g, SDRX_ESTATE, "%s: an earlier call failed on one device after others had gone ahead; destroy the group", what);
     if (n_complex != g->root_frame)
         return gfail(g, SDRX_EINVAL, "frame of %d samples, VFOs were initialised for %d (vfo::init samplesPerBuffer)", n_complex, g->root_frame);
     if (sync_call && g->in_flight > 0)
@@ -414,8 +419,10 @@ int sdrx_group_wait(sdrx_group *g)
             continue;
         int slot = 0;
         const int rc = wait_frame(g->m[k].c, &slot);
-        if (rc)
+        if (rc) {
+            g->broken = true;
             return member_fail(g, (int)k, rc);
+        }
     }
     g->in_flight--;
     group_publish(g);

@@ -46,6 +46,33 @@ def test_trees_bit_exact(key, frames):
             assert np.array_equal(bits(a.taps(which)), bits(b.taps(which)))
 
 
+def test_long_audio_filters_bit_exact():
+    """Pins the oracle where the GPU test of k_lpf_long relies on it: audio low-pass filters far above the
+    shipped profiles' 29-155 taps (filter_bandwidth 500 Hz at 48 kS/s = 925 taps, 35 Hz at 12 kS/s = 3 303
+    taps: longer than a frame's 3 000 outputs), 4 frames, against the real reference build."""
+    _try_reference()
+    t = tp.Topology(fs=1536000, frame=384000, name="longlpf")
+    t.vfos.append(tp.VfoDesc(parent=-1, fs=1536000, decimate_count=3, mixer_freq=-496000.0, demod_usb=False, cstyle=1,
+                             samples_per_buffer=384000))
+    t.vfos.append(tp.VfoDesc(topic="W0", parent=0, fs=192000, decimate_count=2, mixer_freq=-41300.0, filter_bw=500,
+                             gain=tp._g(0.05), cstyle=1, samples_per_buffer=48000))
+    t.vfos.append(tp.VfoDesc(parent=-1, fs=1536000, decimate_count=2, mixer_freq=484000.0, demod_usb=False, cstyle=1,
+                             samples_per_buffer=384000))
+    t.vfos.append(tp.VfoDesc(topic="N0", parent=2, fs=384000, decimate_count=5, mixer_freq=110854.0, filter_bw=35,
+                             gain=tp._g(0.05), cstyle=1, samples_per_buffer=96000))
+    trees = {k: ob.build_tree(k, t) for k in ("port", "reference")}
+    assert [len(trees["reference"][0][i].taps("fir_usb")) for i in (1, 3)] == [925, 3303]
+    lcg = synth.Lcg(8)
+    for f in range(4):
+        iq = synth.lcg_frame(t.frame, lcg) + synth.tone_frame(t.frame, t.fs, [(-496000.0 - 40000.0, 30.0)], f * t.frame)
+        for k in trees:
+            ob.process_roots(trees[k][1], iq)
+        for i in (1, 3):
+            a, b = trees["port"][0][i], trees["reference"][0][i]
+            assert np.array_equal(bits(a.taps("fir_usb")), bits(b.taps("fir_usb")))
+            assert np.array_equal(a.usb(), b.usb()), (f, i)
+
+
 def test_random_designs_and_tables():
     _try_reference()
     rng = np.random.default_rng(5)
