@@ -55,6 +55,33 @@ def _worker(rank, world, port, q):
     bc.result()
     want = synth.Lcg(7)
     assert sums == [float(synth.lcg_frame(topo.frame, want).astype(np.float64).sum()) for _ in range(4)], sums
+    # several frames per collective (what bench.py does at N > 1): one broadcast carries 4 frames
+    bc4 = D.FrameBroadcast(topo.frame, torch.device("cpu"), frames_per_batch=4)
+    lcg4 = synth.Lcg(11)
+    batches = [np.concatenate([synth.lcg_frame(topo.frame, lcg4) for _ in range(4)]) for _ in range(3)]
+    bc4.submit(torch.from_numpy(batches[0]) if rank == 0 else None)
+    for k in range(3):
+        b = bc4.result()
+        for j in range(4):
+            fr = bc4.frame(b, j)
+            assert fr.numel() == 2 * topo.frame
+            assert float(fr.double().sum()) == float(batches[k][j * 2 * topo.frame:(j + 1) * 2 * topo.frame].astype(np.float64).sum()), (k, j)
+        if k + 1 < 3:
+            bc4.submit(torch.from_numpy(batches[k + 1]) if rank == 0 else None)
+    # more ranks than sub VFOs: config 1 has ONE sub, which the partition gives to the last rank; rank 0
+    # holds nothing, still takes part in the broadcast, and no rank turns the main VFO into a leaf
+    c1 = tp.config1()
+    sr1 = D.ShardedReceiver(c1, _OracleEngine)
+    lcg1 = synth.Lcg(2)
+    f1 = synth.lcg_frame(c1.frame, lcg1)
+    sr1.process(torch.from_numpy(f1) if rank == 0 else None)
+    if rank == 0:
+        assert sr1.engine is None and sr1.leaf_topics() == []
+    else:
+        from oracle import binding as ob
+        nodes, roots = ob.build_tree("port", c1)
+        ob.process_roots(roots, f1)
+        assert sr1.leaf_topics() == ["VFO01"] and np.array_equal(sr1.engine.outputs()["VFO01"], nodes[1].usb())
     # weak-scaling bookkeeping the bench uses: totals are sums over ranks
     t = torch.tensor([float(sr.topo.vfo_samples_per_frame())], dtype=torch.float64)
     dist.all_reduce(t)
