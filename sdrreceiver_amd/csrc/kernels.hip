@@ -794,6 +794,32 @@ __device__ __forceinline__ short to_short(double d)
 {
     return (short)(unsigned short)(unsigned)(int)d;
 }
+// The reference's two excursions into double on this path (vfo.cpp:317-328) are kept literally.  Both have
+// an fp32 form with identical results -- the exact difference of two floats rounded to 53 and then to 24
+// bits is the fp32 subtraction (double rounding is innocuous for + - * / when the wide format has
+// >= 2*24 + 2 significand bits), and `float * 2^15` is exact in either format with v_cvt_i32_f32
+// saturating like v_cvt_i32_f64 -- which -DSDRX_DEMOD_F32 selects: all 115 GPU parity tests pass with it,
+// and it is not faster (k_usb_demod 35.8-37.0 vs 35.7-36.6 us on config 3), so the literal form stays.
+__device__ __forceinline__ float usb_difference(float delayed_i, float hilbert)
+{
+#ifndef SDRX_DEMOD_F32
+    return (float)((double)delayed_i - (double)hilbert);
+#else
+    return delayed_i - hilbert;
+#endif
+}
+__device__ __forceinline__ float quantise(float scaled, short &out)
+{
+#ifndef SDRX_DEMOD_F32
+    const double pre = (double)scaled * 32768.0;
+    out = to_short(pre);
+    return (float)pre; // exact: float * 2^15
+#else
+    const float pre = scaled * 32768.0f;
+    out = (short)(unsigned short)(unsigned)(int)pre;
+    return pre;
+#endif
+}
 
 // Late decimation by L in {5,6} (vfo.cpp:334-387 with FIR::FIRUpdateAndProcess/FIRUpdate,
 // dsp.cpp:59-71,150-154): z'[k] = sum_i hd[i] * x[L k - Nd + i]  -- the newest sample x[L k] is
@@ -1101,7 +1127,7 @@ __device__ __forceinline__ void demod_block(const K2Vfo *__restrict__ vfos, cons
         for (int rr = 0; rr < 4; ++rr) {
             const int t = t0 + 2 * rr;
             if (t < ntv)
-                sU[t + soff] = (float)((double)sI[t] - (double)acc[rr]);
+                sU[t + soff] = usb_difference(sI[t], acc[rr]);
         }
     }
     if (tid < 8) // read by the low-pass only under its zero padding taps: must be finite (0 * NaN = NaN)
@@ -1151,10 +1177,7 @@ __device__ __forceinline__ void demod_block(const K2Vfo *__restrict__ vfos, cons
     float pq[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-        const float scaled = u4[rr] * D.gain;
-        const double pre = (double)scaled * 32768.0;
-        o4[rr] = to_short(pre);
-        pq[rr] = (float)pre; // exact: float * 2^15
+        pq[rr] = quantise(u4[rr] * D.gain, o4[rr]);
     }
     if (m + 3 < D.n) {
         v4s o = {o4[0], o4[1], o4[2], o4[3]};
@@ -1250,11 +1273,11 @@ __global__ __launch_bounds__(256) void k_lpf_long(const K4Vfo *__restrict__ vfos
         else
             acc = fmaf(h, w[i], acc);
     }
-    const float scaled = acc * gain;
-    const double pre = (double)scaled * 32768.0;
-    *(SDRX_AS1 short *)(pay + m) = to_short(pre);
+    short q;
+    const float pre = quantise(acc * gain, q);
+    *(SDRX_AS1 short *)(pay + m) = q;
     if (prequant)
-        *(SDRX_AS1 float *)(prequant + m) = (float)pre;
+        *(SDRX_AS1 float *)(prequant + m) = pre;
 }
 
 // vfo::compress (vfo.cpp:389-424): cstyle 1 packs the high nibbles of (re/scalecomp)*128 and
