@@ -740,6 +740,30 @@ def test_long_run_wraps_the_nco_tables_many_times(Receiver):
     rx.close()
 
 
+def test_long_queue_of_frames_through_the_pipeline(Receiver):
+    """64 frames = 16 s of signal queued back to back with sdrx_process_device on the sdr_25E tree (the
+    software pipeline of k_mix_levels stays full for the whole run, every ping-pong buffer flips 64 times,
+    the 384 k / 192 k NCO tables wrap 16 times), with an sdrx_fetch every 16th frame: streams and payloads
+    of the fetched frames bit-identical to the oracle."""
+    import torch
+    topo = golden_topology("profile_25e")
+    rx = Receiver.from_topology(topo, exact=True)
+    nodes, roots = ob.build_tree("port", topo)
+    lcg = synth.Lcg(41)
+    for f in range(64):
+        iq = synth.lcg_frame(topo.frame, lcg) + synth.tone_frame(topo.frame, topo.fs, [(485000.0, 40.0), (-520000.0, 15.0)], f * topo.frame)
+        d = torch.from_numpy(iq).cuda()
+        torch.cuda.synchronize()
+        rx.process_device(d.data_ptr(), topo.frame)
+        ob.process_roots(roots, iq)
+        if f % 16 == 15:
+            rx.fetch()
+            _check_exact(rx, nodes, topo, ("queue", f))
+        else:
+            rx.sync() if f % 16 == 7 else None  # (a drain in the middle of a stretch, too)
+    rx.close()
+
+
 def test_longest_audio_filters(Receiver):
     """The audio low-pass at the top of the supported range: 255 taps (48 k, bw 1817), 251 (bw 1850),
     155 (bw 3000, the 3 kHz case SURVEY lists) and 31 (bw 15000), odd and even history lengths, also
