@@ -18,7 +18,7 @@ mains replicated), raw frames broadcast from rank 0 over RCCL; the weak-scaled c
 
 Timing.  W untimed warm-up steps (plus enough extra to reach ~50 ms of GPU time: the clock ramps),
 then the timed region -- EXACTLY K steps between barrier + torch.cuda.synchronize() on both sides,
-max over ranks -- is repeated R times (default 15); `ms_per_step` and `value` are the MEDIAN
+max over ranks -- is repeated R times (default 25); `ms_per_step` and `value` are the MEDIAN
 repetition, min / max are in `ms_per_step_min/max`.
 
 Prints ONE JSON line (rank 0).  `value` = IQ MSamples/s ingested, summed over every VFO chain of
@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--reps", type=int, default=15, help="repetitions of the timed K-step region (median reported)")
+    ap.add_argument("--reps", type=int, default=25, help="repetitions of the timed K-step region (median reported)")
     ap.add_argument("--workload", default=None)
     ap.add_argument("--fast", action="store_true", help="FMA arithmetic (within 1e-6 of the reference) instead of bit-exact")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

@@ -134,7 +134,6 @@ struct sdrx_ctx {
     unsigned char *h_in[2] = {nullptr, nullptr}; // pinned staging of host-fed frames, per frame parity
     size_t h_in_bytes = 0;
     int in_flight = 0;               // frames submitted (sdrx_submit*) and not yet delivered (sdrx_wait)
-    unsigned long long delivered = 0; // index of the next frame sdrx_wait delivers
     int host_slot = -1;              // which h_pay holds the payloads sdrx_get_output serves
     float2 *d_raw = nullptr;       // staging for host-fed frames (natural order)
     float2 *d_raw_tiled = nullptr; // the raw frame in tile layout: input of the parent-less VFOs
@@ -1469,7 +1468,6 @@ int wait_frame(sdrx_ctx *c, int *slot)
     const int p = (int)(f & 1ull);
     HIPCHK(c, hipEventSynchronize(c->ev_copied[p]));
     c->in_flight--;
-    c->delivered = f + 1;
     c->host_slot = p;
     if (c->in_flight == 0)
         drain_events(c);

@@ -10,7 +10,7 @@ constexpr int kChunk = 64 * kRun;   // 1024 input samples per wave-iteration
 constexpr int kCarry = 16;          // per-stage history window kept in LDS between chunks
 constexpr int kHbHist = 10;         // half-band history carried between frames (x[-1..-10])
 constexpr int kMaxStages = 8;       // vfo.h:63
-constexpr int kMaxLevels = 4;       // tree depth up to which the one-launch frame pipeline is used (the reference builds 2)
+constexpr int kMaxLevels = 4;       // tree depth up to which k_mix_levels (all levels in one launch) is used (the reference builds 2)
 constexpr int kHilbert = 125;       // vfo.cpp:137
 constexpr int kHilbertNz = 62;      // non-zero Hilbert taps (odd indices 1..123)
 constexpr int kDelay = 62;          // vfo.cpp:136
