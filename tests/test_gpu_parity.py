@@ -918,3 +918,35 @@ def test_three_level_tree(Receiver):
         _check_exact(rx, nodes, t, ("3level", f))
     assert [p[0] for p in rx.published] == [b"L2A\0\0", b"L2B\0\0", b"L2C\0\0"]
     rx.close()
+
+
+def test_five_level_tree_takes_the_per_level_launches(Receiver):
+    """Deeper than k_mix_levels' four levels: raw -> d=1 -> d=1 -> d=1 -> d=1 -> {USB leaf, IQ leaf}; the
+    library falls back to one launch per level, queued frames included."""
+    import torch
+    t = tp.Topology(fs=1536000, frame=384000, name="5level")
+    fs, n, parent = 1536000, 384000, -1
+    for lv in range(4):
+        t.vfos.append(tp.VfoDesc(parent=parent, fs=fs, decimate_count=1, mixer_freq=float(40000 - 9000 * lv), demod_usb=False, cstyle=1,
+                                 samples_per_buffer=n))
+        parent, fs, n = len(t.vfos) - 1, fs // 2, n // 2
+    t.vfos.append(tp.VfoDesc(topic="DEEP", parent=parent, fs=fs, decimate_count=1, mixer_freq=1234.0, filter_bw=10000, gain=tp._g(0.05),
+                             cstyle=1, samples_per_buffer=n))
+    t.vfos.append(tp.VfoDesc(topic="DEEPQ", parent=parent, fs=fs, decimate_count=2, mixer_freq=-4321.0, demod_usb=False, cstyle=1,
+                             scalecomp=2, samples_per_buffer=n))
+    rx = Receiver.from_topology(t, exact=True)
+    assert rx.stats()["n_levels"] == 5
+    nodes, roots = ob.build_tree("port", t)
+    frames = [iq for _, iq in _frames(t, 5, seed=14, tones=[(30000.0, 25.0)])]
+    for f in range(2):
+        rx.process(frames[f])
+        ob.process_roots(roots, frames[f])
+        _check_exact(rx, nodes, t, ("5level", f))
+    dev = [torch.from_numpy(iq).cuda() for iq in frames[2:]]
+    torch.cuda.synchronize()
+    for f, d in enumerate(dev):
+        rx.process_device(d.data_ptr(), t.frame)
+        ob.process_roots(roots, frames[2 + f])
+    rx.fetch()
+    _check_exact(rx, nodes, t, ("5level", "queued"))
+    rx.close()
