@@ -49,7 +49,40 @@ int main(void)
     if (rc != SDRX_OK)
         goto fail;
     sdrx_destroy(ctx);
-    return n_messages == 1 ? 0 : 4;
+    ctx = NULL;
+    if (n_messages != 1)
+        return 4;
+    /* the same chain on a device LIST (two shards on the one GPU), pipelined: submit(f+1); wait() -> f */
+    {
+        sdrx_group *grp = NULL;
+        const int devices[2] = {0, 0};
+        int f, rc2 = sdrx_group_create(&grp, devices, 2);
+        if (rc2 == SDRX_OK)
+            rc2 = sdrx_group_add_vfo(grp, &main_vfo, &id_main);
+        sub.parent_id = id_main;
+        if (rc2 == SDRX_OK)
+            rc2 = sdrx_group_add_vfo(grp, &sub, &id_sub);
+        if (rc2 == SDRX_OK)
+            rc2 = sdrx_group_set_publish_callback(grp, on_publish, NULL);
+        if (rc2 == SDRX_OK)
+            rc2 = sdrx_group_finalize(grp);
+        iq = (float *)calloc(2 * 384000, sizeof(float));
+        for (f = 0; f < 3 && rc2 == SDRX_OK; ++f) {
+            rc2 = sdrx_group_submit(grp, iq, 384000);
+            if (rc2 == SDRX_OK && f > 0)
+                rc2 = sdrx_group_wait(grp);
+        }
+        if (rc2 == SDRX_OK)
+            rc2 = sdrx_group_wait(grp);
+        free(iq);
+        if (rc2 != SDRX_OK) {
+            fprintf(stderr, "sdrx_group error %d: %s\n", rc2, sdrx_group_last_error(grp));
+            sdrx_group_destroy(grp);
+            return 6;
+        }
+        sdrx_group_destroy(grp);
+    }
+    return n_messages == 4 ? 0 : 7;
 fail:
     fprintf(stderr, "sdrx error %d: %s\n", rc, sdrx_last_error(ctx));
     sdrx_destroy(ctx);

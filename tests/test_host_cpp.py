@@ -129,7 +129,8 @@ def test_c99_program_over_the_abi():
     _build()
     r = subprocess.run([os.path.join(ROOT, "host", "abi_check")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert "published VFO01 rate 12000 bytes 6000" in r.stdout
+    # one frame through sdrx_process, then three through sdrx_group_submit / _wait on a two-entry device list
+    assert r.stdout.count("published VFO01 rate 12000 bytes 6000") == 4
 
 
 @pytest.mark.gpu
