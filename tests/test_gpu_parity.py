@@ -950,3 +950,117 @@ def test_five_level_tree_takes_the_per_level_launches(Receiver):
     rx.fetch()
     _check_exact(rx, nodes, t, ("5level", "queued"))
     rx.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_interleaving_of_the_frame_interfaces(Receiver, seed):
+    """One receiver, 48 frames, fed through a seeded random interleaving of every way a frame can enter --
+    sdrx_process (synchronous), sdrx_submit / sdrx_wait (pipelined egress, one or two frames in flight),
+    sdrx_process_u8, sdrx_process_device (queued on the device, software-pipelined launches) with
+    sdrx_fetch / sdrx_sync / getters at random points -- the transitions between the launch paths drain
+    and refill the pipelines.  Every payload that comes out (callbacks of a wait / process / fetch) equals
+    the oracle's for the frame it belongs to; the filter state carried across all transitions is one stream."""
+    import torch
+    rng = np.random.default_rng(900 + seed)
+    topo = golden_topology("54w" if seed % 2 else "profile_25e")
+    rx = Receiver.from_topology(topo, exact=True)
+    nodes, roots = ob.build_tree("port", topo)
+    order = topo.leaves_in_publish_order()
+    lcg = synth.Lcg(seed)
+    want, frames = [], []
+    for f in range(48):
+        iq = synth.lcg_frame(topo.frame, lcg)  # integer valued: also representable as dongle bytes
+        ob.process_roots(roots, iq)
+        frames.append(iq)
+        want.append([(nodes[i].usb() if topo.vfos[i].demod_usb else nodes[i].iq()).tobytes() for i in order
+                     if topo.vfos[i].demod_usb or topo.vfos[i].topic])
+    pending = []  # frames submitted and not yet waited for
+    f, checked, keep = 0, 0, []
+
+    def delivered(idx):
+        nonlocal checked
+        assert [p for _, _, p in rx.published] == want[idx], (seed, idx)
+        checked += 1
+
+    while f < 48:
+        op = rng.integers(0, 5)
+        if op == 0 and not pending:
+            rx.process(frames[f])
+            delivered(f)
+            f += 1
+        elif op == 1 and not pending:
+            rx.process_u8((frames[f] + 127).astype(np.uint8))
+            delivered(f)
+            f += 1
+        elif op == 2:
+            if len(pending) == 2:
+                rx.wait()
+                delivered(pending.pop(0))
+            rx.submit(frames[f])
+            pending.append(f)
+            f += 1
+        elif op == 3 and pending:
+            rx.wait()
+            delivered(pending.pop(0))
+        elif op == 4 and not pending:
+            k = int(rng.integers(1, 5))
+            for _ in range(min(k, 48 - f)):
+                d = torch.from_numpy(frames[f]).cuda()
+                torch.cuda.synchronize()
+                keep.append(d)
+                rx.process_device(d.data_ptr(), topo.frame)
+                f += 1
+            what = rng.integers(0, 3)
+            if what == 0:
+                rx.fetch()
+                delivered(f - 1)
+            elif what == 1:
+                rx.sync()
+                assert rx.output(order[0]).tobytes() == want[f - 1][0]
+            keep = keep[-8:]
+    while pending:
+        rx.wait()
+        delivered(pending.pop(0))
+    rx.close()
+    assert checked >= 12, checked
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_interleaving_on_a_group(seed):
+    """The same idea on a group of three contexts (sdrx_group_*): synchronous and pipelined calls, float and
+    byte frames in random order; every delivered frame equals the oracle's, in the reference's publish order."""
+    from sdrreceiver_amd.receiver import Group
+    rng = np.random.default_rng(70 + seed)
+    topo = tp.config3(48)
+    g = Group.from_topology(topo, [0, 0, 0])
+    nodes, roots = ob.build_tree("port", topo)
+    order = topo.leaves_in_publish_order()
+    lcg = synth.Lcg(seed)
+    frames, want = [], []
+    for f in range(24):
+        iq = synth.lcg_frame(topo.frame, lcg)
+        ob.process_roots(roots, iq)
+        frames.append(iq)
+        want.append([nodes[i].usb().tobytes() for i in order])
+    pending, f, checked = [], 0, 0
+    while f < 24 or pending:
+        op = rng.integers(0, 4)
+        if op == 0 and not pending and f < 24:
+            g.process(frames[f])
+            assert [p for _, _, p in g.published] == want[f], (seed, f)
+            f += 1
+            checked += 1
+        elif op in (1, 2) and f < 24:
+            if len(pending) == 2:
+                g.wait()
+                assert [p for _, _, p in g.published] == want[pending.pop(0)]
+                checked += 1
+            (g.submit_u8((frames[f] + 127).astype(np.uint8)) if op == 2 else g.submit(frames[f]))
+            pending.append(f)
+            f += 1
+        elif pending:
+            g.wait()
+            assert [p for _, _, p in g.published] == want[pending.pop(0)]
+            checked += 1
+    g.close()
+    assert checked == 24
