@@ -1334,8 +1334,9 @@ int check_frame_call(sdrx_ctx *c, const char *what, const void *ptr, int n_compl
     return SDRX_OK;
 }
 
-// host frame -> the library's pinned staging buffer of this frame parity -> device.  The buffer's
-// previous user is frame f-2, which has been delivered (or fetched), so its copy is long done.
+// host frame -> the library's pinned staging buffer of this frame parity -> device.  The pinned buffer's
+// previous user is frame f-2, which has been delivered (at most two frames are in flight), so its copy is
+// long done; the device buffer is written and read on `stream` only, in order.
 int stage_host_frame(sdrx_ctx *c, const void *src, size_t bytes, void *dst_dev)
 {
     const int p = (int)(c->frame_no & 1ull);
@@ -1348,8 +1349,6 @@ int stage_host_frame(sdrx_ctx *c, const void *src, size_t bytes, void *dst_dev)
         }
         c->h_in_bytes = (size_t)c->root_frame * sizeof(float2);
     }
-    if (c->pending_fetch) // frames queued by sdrx_process_device and never fetched may still be reading it
-        HIPCHK(c, hipStreamSynchronize(c->stream));
     memcpy(c->h_in[p], src, bytes);
     HIPCHK(c, hipMemcpyAsync(dst_dev, c->h_in[p], bytes, hipMemcpyHostToDevice, c->stream));
     return SDRX_OK;
