@@ -468,8 +468,10 @@ def main():
         out["kernels"] = kernels
         if abi:
             out["through_abi"] = abi
-            out["ms_per_step_through_abi"] = abi["pipelined_pageable_ms"]
-            out["ms_per_step_with_payload_d2h"] = abi["sync_pageable_ms"]
+            ch = abi.get("c_host") if isinstance(abi.get("c_host"), dict) else {}
+            # what a C host sees (host/abi_bench.c) where it ran, else the same loops through ctypes
+            out["ms_per_step_through_abi"] = ch.get("sdrx_submit_wait_ms", abi["pipelined_pageable_ms"])
+            out["ms_per_step_with_payload_d2h"] = ch.get("sdrx_process_ms", abi["sync_pageable_ms"])
         if weak:
             out["weak_config3"] = weak
         if world == 1 and args.configs1:
