@@ -123,13 +123,14 @@ def cpu_baseline(workload):
 def pmc_for(workload, exact):
     """profiles/current_pmc.json (tools/profile.sh + tools/pmc_summary.py): per-launch counter means of
     the committed PMC passes, if they were taken on this workload and arithmetic."""
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "current_pmc.json")))
-    except (OSError, ValueError):
-        return None
-    if pm.get("workload") != workload or pm.get("exact") != exact:
-        return None
-    return pm
+    for name in (f"pmc_{workload}.json", "current_pmc.json"):  # per-workload summaries next to the default one
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if pm.get("workload") == workload and pm.get("exact") == exact:
+            return pm
+    return None
 
 
 def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix_chunks):
