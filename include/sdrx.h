@@ -209,6 +209,8 @@ int sdrx_group_process(sdrx_group *grp, const float *iq, int n_complex);
 int sdrx_group_submit(sdrx_group *grp, const float *iq, int n_complex);
 int sdrx_group_submit_u8(sdrx_group *grp, const uint8_t *iq_bytes, int n_complex);
 int sdrx_group_submit_device(sdrx_group *grp, const void *dev_iq_on_first_device, int n_complex, void *producer_stream);
+/* like sdrx_process_device: kernels only, asynchronous; the frame must stay untouched until sdrx_group_sync */
+int sdrx_group_process_device(sdrx_group *grp, const void *dev_iq_on_first_device, int n_complex, void *producer_stream);
 int sdrx_group_wait(sdrx_group *grp);
 int sdrx_group_in_flight(sdrx_group *grp);
 int sdrx_group_sync(sdrx_group *grp);

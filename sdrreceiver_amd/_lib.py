@@ -83,6 +83,7 @@ SYMBOLS = {
     "sdrx_group_submit": (_i, [_vp, _vp, _i]),
     "sdrx_group_submit_u8": (_i, [_vp, _vp, _i]),
     "sdrx_group_submit_device": (_i, [_vp, _vp, _i, _vp]),
+    "sdrx_group_process_device": (_i, [_vp, _vp, _i, _vp]),
     "sdrx_group_wait": (_i, [_vp]),
     "sdrx_group_in_flight": (_i, [_vp]),
     "sdrx_group_sync": (_i, [_vp]),

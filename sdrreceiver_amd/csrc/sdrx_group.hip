@@ -408,6 +408,18 @@ int sdrx_group_submit_device(sdrx_group *g, const void *dev_iq, int n_complex, v
     return group_enqueue(g, dev_iq, (size_t)n_complex * sizeof(float2), kRawF32, true);
 }
 
+// The device-resident frame without the payload copies (cf. sdrx_process_device): every member queues its
+// kernels and returns; sdrx_group_sync waits for all of them, sdrx_group_get_output fetches on demand.
+int sdrx_group_process_device(sdrx_group *g, const void *dev_iq, int n_complex, void *producer_stream)
+{
+    int rc = group_check(g, "sdrx_group_process_device", dev_iq, n_complex, true);
+    if (rc)
+        return rc;
+    GHIP(g, hipSetDevice(g->m[0].device));
+    GHIP(g, hipEventRecord(g->ev_ready[g->frame_no & 1ull], producer_stream ? reinterpret_cast<hipStream_t>(producer_stream) : g->stage_stream));
+    return group_enqueue(g, dev_iq, (size_t)n_complex * sizeof(float2), kRawF32, false);
+}
+
 int sdrx_group_wait(sdrx_group *g)
 {
     if (!g)

@@ -265,6 +265,9 @@ class Group:
     def submit_device(self, dev_ptr: int, n_complex: int, producer_stream: int | None = None) -> None:
         self._chk(self.L.sdrx_group_submit_device(self.h, C.c_void_p(dev_ptr), int(n_complex), C.c_void_p(producer_stream or 0)))
 
+    def process_device(self, dev_ptr: int, n_complex: int, producer_stream: int | None = None) -> None:
+        self._chk(self.L.sdrx_group_process_device(self.h, C.c_void_p(dev_ptr), int(n_complex), C.c_void_p(producer_stream or 0)))
+
     def wait(self) -> None:
         self.published.clear()
         self._chk(self.L.sdrx_group_wait(self.h))

@@ -377,6 +377,16 @@ def test_group_of_contexts_in_one_process(members, key):
         g.wait()
         ob.process_roots(roots, ob.u8_to_float(b))
         assert g.published == want()
+    import torch  # frames that are already on the first device, queued without payload copies
+    dev = [torch.from_numpy(iq).cuda() for iq in frames[:3]]
+    torch.cuda.synchronize()
+    for f, d in enumerate(dev):
+        g.process_device(d.data_ptr(), topo.frame)
+        ob.process_roots(roots, frames[f])
+    g.sync()
+    for i in order:
+        ref = nodes[i].usb() if topo.vfos[i].demod_usb else nodes[i].iq()
+        assert np.array_equal(g.output(i), ref), (key, members, "device", i)
     st = g.member_stats()
     assert sum(s["n_leaves"] for s in st if s) == len(order)
     g.close()
