@@ -787,12 +787,14 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
 }
 
 // ------------------------------------------------------------------------------------ demod tail
-// `short = double` of the reference's x86-64 build (vfo.cpp:328,364): truncate toward zero to
-// int32, keep the low 16 bits.  v_cvt_i32_f64 truncates and saturates; in-range values (all
-// that the reference defines) agree.
+// `short = double` of the reference's x86-64 build (vfo.cpp:328,364): cvttsd2si truncates toward zero to
+// int32 and yields INT32_MIN ("integer indefinite") for anything outside int32 or NaN; the low 16 bits are
+// kept.  (The C standard calls the out-of-range case undefined; this is what the reference's binary does,
+// and what the oracle restates.)  v_cvt_i32_f64 truncates the same way but SATURATES, hence the select.
 __device__ __forceinline__ short to_short(double d)
 {
-    return (short)(unsigned short)(unsigned)(int)d;
+    const int t = (d >= -2147483648.0 && d < 2147483648.0) ? (int)d : (int)0x80000000;
+    return (short)(unsigned short)(unsigned)t;
 }
 // The reference's two excursions into double on this path (vfo.cpp:317-328) are kept literally.  Both have
 // an fp32 form with identical results -- the exact difference of two floats rounded to 53 and then to 24
@@ -812,11 +814,12 @@ __device__ __forceinline__ float quantise(float scaled, short &out)
 {
 #ifndef SDRX_DEMOD_F32
     const double pre = (double)scaled * 32768.0;
-    out = to_short(pre);
+    // |pre| < 2^31 <=> |scaled| < 2^16 (the product is exact): the range test of to_short() as ONE fp32 compare
+    out = fabsf(scaled) < 65536.0f ? (short)(unsigned short)(unsigned)(int)pre : (short)0;
     return (float)pre; // exact: float * 2^15
 #else
     const float pre = scaled * 32768.0f;
-    out = (short)(unsigned short)(unsigned)(int)pre;
+    out = (short)(unsigned short)(unsigned)((pre >= -2147483648.0f && pre < 2147483648.0f) ? (int)pre : (int)0x80000000);
     return pre;
 #endif
 }
@@ -1282,9 +1285,10 @@ __global__ __launch_bounds__(256) void k_lpf_long(const K4Vfo *__restrict__ vfos
 
 // vfo::compress (vfo.cpp:389-424): cstyle 1 packs the high nibbles of (re/scalecomp)*128 and
 // (im/scalecomp)*128 into one byte; otherwise two int8 per sample.
-__device__ __forceinline__ int to_schar(float f)
+__device__ __forceinline__ int to_schar(float f) // cvttss2si + the low 8 bits: out of int32 range or NaN -> INT32_MIN -> 0
 {
-    return (int)(signed char)(unsigned char)(unsigned)(int)f;
+    const int t = (f >= -2147483648.0f && f < 2147483648.0f) ? (int)f : (int)0x80000000;
+    return (int)(signed char)(unsigned char)(unsigned)t;
 }
 __global__ __launch_bounds__(256) void k_compress(const K3Vfo *__restrict__ vfos, const BlockWork *__restrict__ work,
                                                   unsigned long long frame_no)

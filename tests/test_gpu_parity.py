@@ -1074,3 +1074,35 @@ def test_random_interleaving_on_a_group(seed):
             checked += 1
     g.close()
     assert checked == 24
+
+
+def test_out_of_range_conversions_follow_the_x86_build(Receiver):
+    """`short = double` and `signed char = float` beyond the target range are undefined in C; the reference's
+    x86-64 binary does cvttsd2si / cvttss2si -- INT32_MIN for anything outside int32, then the low 16 / 8
+    bits -- and so does the oracle.  A frame 200 000 times louder than the 8-bit front end can deliver drives
+    every leaf far out of range (audio beyond int16 AND beyond int32, IQ bytes beyond int8): the payloads
+    still equal the oracle's bit for bit, as do the pre-quantisation floats."""
+    t = tp.Topology(fs=1536000, frame=384000, name="loud")
+    t.vfos.append(tp.VfoDesc(parent=-1, fs=1536000, decimate_count=2, mixer_freq=484000.0, demod_usb=False, cstyle=1,
+                             samples_per_buffer=384000))
+    t.vfos.append(tp.VfoDesc(topic="LOUD1", parent=0, fs=384000, decimate_count=5, mixer_freq=110854.0, filter_bw=4000,
+                             gain=tp._g(0.05), cstyle=1, samples_per_buffer=96000))
+    t.vfos.append(tp.VfoDesc(topic="LOUD2", parent=0, fs=384000, decimate_count=3, mixer_freq=-20000.0, gain=tp._g(0.8), cstyle=1,
+                             samples_per_buffer=96000))
+    for cs, top in ((1, "IQ4"), (0, "IQ8")):
+        t.vfos.append(tp.VfoDesc(topic=top, parent=-1, fs=1536000, decimate_count=3, mixer_freq=-496000.0, demod_usb=False,
+                                 cstyle=cs, scalecomp=1, samples_per_buffer=384000))
+    rx = Receiver.from_topology(t, exact=True, keep_prequant=True)
+    nodes, roots = ob.build_tree("port", t)
+    seen_wrap = False
+    for f, iq in _frames(t, 3, seed=3, tones=[(484000.0 + 111000.0, 9.0), (-496000.0 + 3000.0, 5.0)]):
+        iq = (iq * np.float32(200000.0)).astype(np.float32)
+        rx.process(iq)
+        ob.process_roots(roots, iq)
+        _check_exact(rx, nodes, t, ("loud", f))
+        for i in (1, 2):
+            pre = nodes[i].usb_prequant()
+            assert np.array_equal(rx.prequant(i).astype(np.float64), pre), (f, i)
+            seen_wrap |= bool((np.abs(pre) >= 2.0 ** 31).any()) and bool((np.abs(pre) > 40000).any())
+    rx.close()
+    assert seen_wrap, "the test signal must drive the audio beyond int32"
