@@ -703,7 +703,7 @@ int sdrx_check_vfo(const sdrx_vfo_desc *d, char *msg, size_t cap)
         if (const char *why = low_pass_rejection((double)target * d->late_decimate, (double)(target / 2), (double)target / (d->late_decimate - 1)))
             return say(SDRX_EFILTER, "%s", why);
     }
-    if (d->demod_usb && d->filter_bw_hz > 0)
+    if (d->filter_bw_hz > 0) // (vfo::init designs this filter for ANY vfo with filterbw > 0, vfo.cpp:106-124, USB or not)
         if (const char *why = low_pass_rejection((double)target, (double)d->filter_bw_hz, (double)d->filter_bw_hz / 4))
             return say(SDRX_EFILTER, "%s", why);
     if (d->fs % kRun || d->samples_per_buffer % kRun || d->fs < kChunk)

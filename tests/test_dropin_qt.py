@@ -83,7 +83,7 @@ def test_init_throws_where_the_reference_throws():
     ref = _probe("ref")
     assert ref["ok"][0] == 0 and ref["bw_exactly_half_rate"][0] == 0 and ref["late_ok"][0] == 0
     assert ref["bw_above_half_rate"] == [1, "firdes check failed: 0 < fa <= sampling_freq / 2"]
-    assert ref["late_bw_too_wide"][0] == 1
+    assert ref["late_bw_too_wide"][0] == 1 and ref["non_usb_with_a_bad_bandwidth"][0] == 1
     assert _probe("sdrx") == ref
 
 

@@ -53,6 +53,7 @@ def probe(kind):
         "late_ok": replace(base, fs=240000, decimate_count=0, late_decimate=5, filter_bw=10000, samples_per_buffer=60000),
         "late_bw_too_wide": replace(base, fs=240000, decimate_count=0, late_decimate=5, filter_bw=30000, samples_per_buffer=60000),
         "main_is_never_filtered": replace(base, demod_usb=False, filter_bw=0),
+        "non_usb_with_a_bad_bandwidth": replace(base, demod_usb=False, filter_bw=7000),  # designed (and rejected) all the same
     }
     addr = f"ipc:///tmp/sdrx_dropin_probe_{os.getpid()}".encode()
     out = {}
