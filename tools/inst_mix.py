@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""tools/inst_mix.py [kernels.s] -- static instruction mix of the mix/decimate item in the compiled ISA
+(`make -C sdrreceiver_amd/csrc asm` writes kernels.s), next to what the source demands:
+
+  per 1024-sample chunk of a d = 5 VFO, one wave (a packed v_pk_*_f32 on a (re, im) pair = ONE instruction)
+    NCO replay  16 x (cmul: 2 pk_mul + 1 pk_fma; n*n: 1 pk_mul; x+y, 1.95-s: 2 scalar; n*norm: 1 pk_mul) = 112
+    mix         16 x (cmul: 2 pk_mul + 1 pk_fma)                                                          =  48
+    stage 0      8 x (3 pair sums + 4 products + 3 sums + (0 + s))  [4 pk_mul + 7 pk_add]                 =  88
+    stage 1      4 x the same                                                                             =  44
+    halos       16 complex values shifted one lane (wave_shr:1), 2 v_mov_b32_dpp each                     =  32
+    LDS stages  one rolled instance of the same 11-instruction dot product (run 2 + 1 + 1 times per lane)
+
+The register-resident part is straight-line code, so the STATIC counts of the kernel must be exactly
+  v_pk_mul_f32 = 64 + 32 + 32 + 16 + 4 = 148,  v_pk_add_f32 = 56 + 28 + 7 = 91,  v_pk_fma_f32 = 16 + 16 = 32,  *_dpp = 32
+which this script checks (exact arithmetic, level >= 1 instantiation)."""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "sdrreceiver_amd", "csrc", "kernels.s")
+lines = open(path).read().splitlines()
+want = {"v_pk_mul_f32": 148, "v_pk_add_f32": 91, "v_pk_fma_f32": 32, "dpp": 32}
+ok = True
+for sym, label in (("_ZN4sdrx14k_mix_decimateILb1ELi1EEE", "k_mix_decimate<exact, level>=1>"), ("_ZN4sdrx12k_mix_levelsILb1EEE", "k_mix_levels<exact>")):
+    start = next((i for i, l in enumerate(lines) if l.startswith(sym) and l.rstrip().endswith(":") or (l.startswith(sym) and ": " in l)), None)
+    if start is None:
+        print(f"{label}: not found in {path}")
+        ok = False
+        continue
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    body = [l.strip() for l in lines[start:end] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+    mn = [l.split()[0] for l in body if l]
+    count = {k: sum(1 for m in mn if m == k) for k in ("v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32")}
+    count["dpp"] = sum(1 for l in body if re.search(r"\b(row_|wave_)\w+:\d", l))
+    other = {"valu_total": sum(1 for m in mn if m.startswith("v_")), "ds": sum(1 for m in mn if m.startswith("ds_")),
+             "global": sum(1 for m in mn if m.startswith("global_")), "salu+smem": sum(1 for m in mn if m.startswith("s_")),
+             "scratch": sum(1 for m in mn if m.startswith("scratch_"))}
+    good = all(count[k] == want[k] for k in want)
+    ok &= good
+    print(f"{label}: {count}  {'== source count' if good else '!= source count ' + str(want)}  (static totals: {other})")
+sys.exit(0 if ok else 1)

@@ -64,7 +64,8 @@ def main():
                 avg_us[k] = float(r["AverageNs"]) / 1e3
     res = {"source": os.path.relpath(d), "git_sha": sha, "workload": workload, "exact": exact, "kernels": {},
            "inst_mix": {"k_mix_decimate, d=5 sub VFO, per 1024-sample chunk (source count, packed = 1)": INST_MIX_D5,
-                        "sum": sum(INST_MIX_D5.values())},
+                        "sum": sum(INST_MIX_D5.values()),
+                        "isa_check": "tools/inst_mix.py: static v_pk_mul/add/fma_f32 = 148/91/32 and 32 DPP moves in kernels.s == the source count"},
            "note": "per-launch medians; hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE correction)"}
     for k, c in agg.items():
         # median over the dispatches: a few launches of a run differ in shape (pipeline fill / drain)
