@@ -194,6 +194,9 @@ def main():
     ap.add_argument("--fast", action="store_true", help="FMA arithmetic (within 1e-6 of the reference) instead of bit-exact")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-abi", action="store_true", help="skip the through-the-ABI (host buffers, PCIe both ways) leg")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side readings of the N = 1 line (north-star 10 240 subs, flat 1 024, config 4): a profiled "
+                         "command must launch the kernels of ONE workload only")
     ap.add_argument("--pipeline", action="store_true", help="leaf tail on a second stream beside the next frame's levels (A/B switch; slower)")
     ap.add_argument("--no-fuse", action="store_true", help="one k_mix_decimate launch per tree level instead of k_mix_levels (A/B switch)")
     ap.add_argument("--no-frame-pipeline", action="store_true", help="k_mix_levels, but every frame runs through all its levels at once (A/B switch)")
@@ -331,25 +334,69 @@ def main():
             if self.rx:
                 self.rx.close()
 
+    def kernel_pass(j, kt_steps):
+        """A separate pass with HIP events around every kernel launch (on the launch's stream): per-kernel
+        average durations, the dominant kernel and the frame's summed kernel time."""
+        kt = {}
+        if j.rx:
+            j.rx.enable_kernel_timing(True)
+            for k in range(kt_steps):
+                j.step(k)
+            j.realign(kt_steps)
+            barrier()
+            kt = j.rx.kernel_times()
+            j.rx.enable_kernel_timing(False)
+        else:
+            barrier()
+        kernels, dom, dom_ms, frame_kernel_ms = {}, None, -1.0, 0.0
+        for name, r in kt.items():
+            if r["launches"] * 2 < kt_steps:
+                continue  # the one or two single-level launches that fill / drain the frame pipeline
+            avg = r["ms"] / r["launches"]
+            per_frame = r["ms"] / kt_steps
+            frame_kernel_ms += per_frame
+            kernels[name] = {"avg_ms": round(avg, 5), "launches_per_frame": int(round(r["launches"] / kt_steps)),
+                             "kernel_bytes_per_launch": r["alg_bytes"] // r["launches"],
+                             "GBps": round(r["alg_bytes"] / r["launches"] / (avg * 1e-3) / 1e9, 1)}
+            if per_frame > dom_ms:
+                dom, dom_ms = name, per_frame
+        return kt, kernels, dom, frame_kernel_ms
+
+    def side_reading(name):
+        """Another workload of BASELINE.json / SURVEY.md 8d on this GPU, measured the same way (clock warm-up,
+        K steps between synchronisations, median of a few repetitions, event-timed kernel pass): a side object
+        of the N = 1 line.  `value` and `ms_per_step` of the line stay those of the default workload."""
+        try:
+            j = Job(name)
+            sreps = j.measure(args.steps, args.warmup, max(1, min(args.reps, 5)))
+            sdt = statistics.median(sreps)
+            ks = min(args.steps, 12)
+            skt, skern, sdom, sfk = kernel_pass(j, ks)
+            fsec = j.full.frame / j.full.fs
+            o = {"workload": j.descr, "sub_vfos": int(j.st["n_leaves"]), "ms_per_step": round(sdt / args.steps * 1e3, 4),
+                 "ms_per_step_min": round(min(sreps) / args.steps * 1e3, 4), "ms_per_step_max": round(max(sreps) / args.steps * 1e3, 4),
+                 "value": round(args.steps * j.st["vfo_samples_per_frame"] / sdt / 1e6, 2), "unit": "MSamples/s",
+                 "realtime_factor": round(fsec / (sdt / args.steps), 1),
+                 "vfos_at_realtime": int(j.st["n_leaves"] * fsec / (sdt / args.steps)),
+                 "algorithmic_GBps_whole_frame": round(args.steps * j.st["algorithmic_bytes_per_frame"] / sdt / 1e9, 1),
+                 "frame_frac": round(args.steps * j.st["algorithmic_bytes_per_frame"] / sdt / 1e9 / HBM_PEAK_GBS, 4)}
+            if sdom:
+                o["roofline"] = roofline_object(sdom, skt[sdom], ks, sfk, j.st["algorithmic_bytes_per_frame"], 1,
+                                                pmc_for(name, not args.fast), j.st["mix_chunks_per_frame"])
+            o["kernels"] = {k: v["avg_ms"] for k, v in skern.items()}
+            j.close()
+            return o
+        except Exception as e:  # the bench line must still come out
+            return {"error": f"{type(e).__name__}: {e}"}
+
     job = Job(workload)
     topo, rx, st, full, descr = job.topo, job.rx, job.st, job.full, job.descr
     reps = job.measure(args.steps, args.warmup, max(1, args.reps))
     dt = statistics.median(reps)
     vfo_samples, alg_bytes, n_leaves = allsum([st["vfo_samples_per_frame"], st["algorithmic_bytes_per_frame"], st["n_leaves"]])
 
-    # second, separate pass with HIP events around every kernel launch (on the launch's stream):
-    # the dominant kernel's average duration for the roofline object
-    kt, kt_steps = {}, min(args.steps, 20)
-    if rx:
-        rx.enable_kernel_timing(True)
-        for k in range(kt_steps):
-            job.step(k)
-        job.realign(kt_steps)
-        barrier()
-        kt = rx.kernel_times()
-        rx.enable_kernel_timing(False)
-    else:
-        barrier()
+    kt_steps = min(args.steps, 20)
+    kt, kernels, dom, frame_kernel_ms = kernel_pass(job, kt_steps)
 
     # third (N = 1): through the C ABI from HOST buffers -- what a Qt / C++ host sees, PCIe both ways.
     abi = None
@@ -389,6 +436,25 @@ def main():
                "note": "host float/byte frame in, int16 payloads in host memory out, publish callbacks off; median of 3"}
         for kind in ("sync_pageable", "sync_pinned", "pipelined_pageable", "pipelined_pinned", "pipelined_u8"):
             abi[kind + "_ms"] = host_loop(kind)
+        # dongle bytes WITH the DC-bias removal of the shipped sdr_25E profile (correct_dc_bias=1, sdrj.cpp:271-286):
+        # the reference's sequentially rounded recurrence, bit for bit, is one wave walking the frame
+        u8 = (job.frames_np[0] + 127).astype(np.uint8)
+        for label, fn in (("u8_dc_sync_ms", lambda: rx.process_u8(u8, correct_dc=True)),):
+            fn()
+            barrier()
+            t1 = time.perf_counter()
+            for _k in range(4):
+                fn()
+            barrier()
+            abi[label] = round((time.perf_counter() - t1) / 4 * 1e3, 4)
+        rx.submit_u8(u8, correct_dc=True)
+        barrier_t = time.perf_counter()
+        for _k in range(1, 6):
+            rx.submit_u8(u8, correct_dc=True)
+            rx.wait()
+        rx.wait()
+        abi["u8_dc_pipelined_ms"] = round((time.perf_counter() - barrier_t) / 6 * 1e3, 4)
+        abi["u8_dc_ms_per_frame"] = abi["u8_dc_pipelined_ms"]
         rx.set_publish(True)
         t1 = time.perf_counter()
         for _k in range(4):
@@ -404,6 +470,13 @@ def main():
                 abi["c_host"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-300:]}
             except Exception as e:
                 abi["c_host"] = {"error": f"{type(e).__name__}: {e}"}
+
+    side = {}
+    if world == 1 and workload == "config3" and not args.no_side:
+        # BASELINE.json's north-star target, SURVEY.md 8d's flat variant ("1.536 MS/s -> 48 kHz chain" read literally)
+        # and config 4, on this same box and build -- side objects; a few hundred ms of GPU time each
+        for key, name in (("north_star_10k", "10k"), ("flat_1024", "flat"), ("config4_256", "config4")):
+            side[key] = side_reading(name)
 
     weak = None
     if world > 1 and workload == "config5":
@@ -426,20 +499,6 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         frame_seconds = full.frame / full.fs
         value = args.steps * vfo_samples / dt / 1e6
-        kernels = {}
-        dom, dom_ms = None, -1.0
-        frame_kernel_ms = 0.0
-        for name, r in kt.items():
-            if r["launches"] * 2 < kt_steps:
-                continue  # the one or two single-level launches that fill / drain the frame pipeline
-            avg = r["ms"] / r["launches"]
-            per_frame = r["ms"] / kt_steps
-            frame_kernel_ms += per_frame
-            kernels[name] = {"avg_ms": round(avg, 5), "launches_per_frame": int(round(r["launches"] / kt_steps)),
-                             "kernel_bytes_per_launch": r["alg_bytes"] // r["launches"],
-                             "GBps": round(r["alg_bytes"] / r["launches"] / (avg * 1e-3) / 1e9, 1)}
-            if per_frame > dom_ms:
-                dom, dom_ms = name, per_frame
         out = {
             "metric": "IQ MSamples/s ingested, summed over VFO chains (1.536 MS/s -> 48/12 kHz USB chain)",
             "value": round(value, 2), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -475,6 +534,8 @@ def main():
             out["ms_per_step_with_payload_d2h"] = ch.get("sdrx_process_ms", abi["sync_pageable_ms"])
         if weak:
             out["weak_config3"] = weak
+        if side:
+            out.update(side)
         if world == 1 and args.configs1:
             # BASELINE.json configs[1] (32 sub VFOs), the same way, as a side reading: a latency-bound
             # plumbing case on this hardware (three ~10 us launches per frame)

@@ -155,28 +155,23 @@ public:
         after_frame(len / 2);
     }
     // rtl_tcp / dongle bytes (sdrj.cpp:149-165): LUT and DC correction on the device.  On several devices
-    // the bytes themselves are fanned out (a quarter of the traffic) unless the DC-bias IIR is on: that
-    // recurrence runs once, on the host as in the reference (sdrj.cpp:155-160,271-286), and floats travel.
+    // the bytes themselves are fanned out (a quarter of the traffic); with the DC-bias IIR on, every device runs
+    // the recurrence itself on the whole frame (same bytes, same start state: the same estimate everywhere).
     void demodBytes(const uint8_t *bytes, int n_complex)
     {
         if (!started())
             start();
         if (!grp_) {
             check(sdrx_process_u8(ctx_, bytes, n_complex, correctDC ? 1 : 0), "sdrx_process_u8");
-        } else if (!correctDC) {
-            if (emitFFT) {
+        } else {
+            if (emitFFT && !correctDC) { // the raw spectrum tap of a group without DC removal: the LUT, here
                 samples_.resize((size_t)2 * n_complex);
                 for (size_t i = 0; i < samples_.size(); ++i)
-                    samples_[i] = (float)((int)bytes[i] - 127);
+                    samples_[i] = (float)((int)bytes[i] - 127); // jonti/sdr.cpp:43-49
+            } else {
+                samples_.clear();
             }
-            check(sdrx_group_submit_u8(grp_, bytes, n_complex), "sdrx_group_submit_u8");
-            check(sdrx_group_wait(grp_), "sdrx_group_wait");
-        } else {
-            samples_.resize((size_t)2 * n_complex);
-            for (size_t i = 0; i < samples_.size(); ++i)
-                samples_[i] = (float)((int)bytes[i] - 127); // jonti/sdr.cpp:43-49
-            dc_correct(samples_);
-            check(sdrx_group_process(grp_, samples_.data(), n_complex), "sdrx_group_process");
+            check(sdrx_group_process_u8(grp_, bytes, n_complex, correctDC ? 1 : 0), "sdrx_group_process_u8");
         }
         after_frame(n_complex);
     }
@@ -225,11 +220,18 @@ private:
             if (fftData) {
                 int n = 0;
                 tap_.resize((size_t)n_complex);
-                if (grp_) { // the frame as the host handed it over (after its own LUT / DC removal)
-                    if (samples_.size() == (size_t)2 * n_complex)
+                if (grp_) { // the frame as the host handed it over (after its own LUT / DC removal) ...
+                    if (samples_.size() == (size_t)2 * n_complex) {
                         std::memcpy(static_cast<void *>(tap_.data()), samples_.data(), sizeof(float) * samples_.size());
-                    else
-                        tap_.clear();
+                    } else { // ... or, bytes with the DC removal done on the devices, as the first one holding VFOs kept it
+                        sdrx_ctx *c = nullptr;
+                        for (int k = 0; k < sdrx_group_size(grp_) && !c; ++k)
+                            check(sdrx_group_member(grp_, k, &c, nullptr), "sdrx_group_member");
+                        if (c && sdrx_get_raw(c, reinterpret_cast<float *>(tap_.data()), n_complex, &n) == SDRX_OK)
+                            tap_.resize((size_t)n);
+                        else
+                            tap_.clear();
+                    }
                 } else {
                     check(sdrx_get_raw(ctx_, reinterpret_cast<float *>(tap_.data()), n_complex, &n), "sdrx_get_raw");
                     tap_.resize((size_t)n);

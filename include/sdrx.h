@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SDRX_ABI_VERSION 2
+#define SDRX_ABI_VERSION 3
 
 enum {
     SDRX_OK = 0,
@@ -90,6 +90,13 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
  *            back; results are bit-identical.  Measured on MI355X (profiles/README.md): the two
  *            kernels then share a VALU-bound machine and both stretch -- 0.119 vs 0.109 ms per
  *            frame on BASELINE config 3 -- so it is off by default and kept as an A/B switch.
+ *   "fuse" 1 (default) | 0: frames queued on the device (sdrx_process_device) run the mix/decimate items
+ *            of ALL tree levels in one launch (k_mix_levels); 0 = one launch per tree level (A/B switch).
+ *   "frame_pipeline" 1 (default) | 0: with "fuse", level l of that one launch works on frame k - l (a
+ *            software pipeline over the frames queued back to back), so a frame queued with
+ *            sdrx_process_device is only COMPLETE after the next such call or after sdrx_sync /
+ *            sdrx_fetch / sdrx_get_* (which run what is outstanding).  0 = every call runs its frame through
+ *            all levels at once.  Results are bit-identical either way.
  *   "dc_blocked_scan" 0|1 (default 0): how sdrx_process_u8 removes the DC bias.  0 = the
  *                 reference's sequentially rounded fp32 recurrence, bit for bit (one wave,
  *                 ~1.7 ms per 384 000-sample frame).  1 = the same linear filter as a blocked
@@ -150,8 +157,10 @@ int sdrx_set_stream(sdrx_ctx *ctx, void *hip_stream);
  * SDRX_MAX_IN_FLIGHT frames may be submitted and not yet delivered (SDRX_ESTATE otherwise).
  * The steady state of a streaming host is  submit(f+1); wait() -> f;  i.e. one frame of latency in
  * exchange for PCIe and kernels running concurrently.  sdrx_process* are submit + wait of one frame.
- * While frames are in flight the synchronous calls (sdrx_process*, sdrx_fetch, sdrx_get_*) return
- * SDRX_ESTATE. */
+ * While frames are in flight sdrx_get_output keeps serving the last DELIVERED frame (its payloads sit in
+ * host memory); the synchronous calls (sdrx_process*, sdrx_fetch) and the device read-backs
+ * (sdrx_get_stream, sdrx_get_raw, sdrx_get_prequant) return SDRX_ESTATE -- the device buffers behind them
+ * already belong to a newer frame.  sdrx_get_kernel_times waits for everything queued. */
 #define SDRX_MAX_IN_FLIGHT 2
 int sdrx_submit(sdrx_ctx *ctx, const float *iq, int n_complex);
 int sdrx_submit_u8(sdrx_ctx *ctx, const uint8_t *iq_bytes, int n_complex, int correct_dc);
@@ -201,13 +210,22 @@ int sdrx_group_create(sdrx_group **grp, const int *device_ordinals, int n_device
 int sdrx_group_destroy(sdrx_group *grp);
 const char *sdrx_group_last_error(const sdrx_group *grp); /* grp may be NULL: error of a failed create */
 int sdrx_group_size(const sdrx_group *grp);
+/* 1: every member reaches the first device's frame buffer directly (same device, or peer access enabled: one
+ * xGMI link per peer, the N-1 copies run at once); 0: the runtime stages at least one peer copy through host
+ * memory (still correct, slower) -- sdrx_group_last_error() right after sdrx_group_create names the device. */
+int sdrx_group_peer_access(const sdrx_group *grp);
 int sdrx_group_add_vfo(sdrx_group *grp, const sdrx_vfo_desc *desc, int *id_out);
 int sdrx_group_set_option(sdrx_group *grp, const char *name, int value); /* applied to every member */
 int sdrx_group_set_publish_callback(sdrx_group *grp, sdrx_publish_fn fn, void *user);
 int sdrx_group_finalize(sdrx_group *grp);
 int sdrx_group_process(sdrx_group *grp, const float *iq, int n_complex);
 int sdrx_group_submit(sdrx_group *grp, const float *iq, int n_complex);
-int sdrx_group_submit_u8(sdrx_group *grp, const uint8_t *iq_bytes, int n_complex);
+/* Dongle bytes: a quarter of the bytes cross PCIe and xGMI, every device applies the b - 127 LUT itself
+ * (jonti/sdr.cpp:43-49) and, if correct_dc != 0, the DC-bias IIR of sdrj.cpp:271-286 on the whole frame with
+ * an accumulator of its own -- identical bytes and identical start state keep the devices' estimates
+ * identical, so only the bytes travel.  What the shipped sdr_25E.ini (correct_dc_bias=1) needs. */
+int sdrx_group_submit_u8(sdrx_group *grp, const uint8_t *iq_bytes, int n_complex, int correct_dc);
+int sdrx_group_process_u8(sdrx_group *grp, const uint8_t *iq_bytes, int n_complex, int correct_dc);
 int sdrx_group_submit_device(sdrx_group *grp, const void *dev_iq_on_first_device, int n_complex, void *producer_stream);
 /* like sdrx_process_device: kernels only, asynchronous; the frame must stay untouched until sdrx_group_sync */
 int sdrx_group_process_device(sdrx_group *grp, const void *dev_iq_on_first_device, int n_complex, void *producer_stream);

@@ -81,7 +81,9 @@ SYMBOLS = {
     "sdrx_group_finalize": (_i, [_vp]),
     "sdrx_group_process": (_i, [_vp, _vp, _i]),
     "sdrx_group_submit": (_i, [_vp, _vp, _i]),
-    "sdrx_group_submit_u8": (_i, [_vp, _vp, _i]),
+    "sdrx_group_submit_u8": (_i, [_vp, _vp, _i, _i]),
+    "sdrx_group_process_u8": (_i, [_vp, _vp, _i, _i]),
+    "sdrx_group_peer_access": (_i, [_vp]),
     "sdrx_group_submit_device": (_i, [_vp, _vp, _i, _vp]),
     "sdrx_group_process_device": (_i, [_vp, _vp, _i, _vp]),
     "sdrx_group_wait": (_i, [_vp]),

@@ -1368,18 +1368,14 @@ int enqueue_f32(sdrx_ctx *c, const float *iq, int n_complex, bool egress)
     return rc;
 }
 
-int enqueue_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correct_dc, bool egress)
+// `dev_bytes`: the frame's dongle bytes, already on this context's device and complete in the order of
+// c->stream.  LUT (+ the DC-bias IIR with this context's own accumulator) and the frame itself.
+int enqueue_u8_device(sdrx_ctx *c, const void *dev_bytes, int n_complex, int correct_dc, bool egress)
 {
-    int rc = ensure_raw(c, (size_t)c->root_frame);
-    if (rc)
-        return rc;
-    if (!c->d_dc_state) {
+    if (correct_dc && !c->d_dc_state) {
         HIPCHK(c, hipMalloc(&c->d_dc_state, 4 * sizeof(float)));
         HIPCHK(c, hipMemsetAsync(c->d_dc_state, 0, 4 * sizeof(float), c->stream)); // `static cpx_typef avept=0`, sdrj.cpp:279
     }
-    rc = stage_host_frame(c, bytes, (size_t)n_complex * 2, c->d_raw_u8);
-    if (rc)
-        return rc;
     int mode = kRawU8;
     const int nchunks = (n_complex + kChunk - 1) / kChunk;
     if (correct_dc && c->opt_dc_blocked && !c->d_dc_tab) {
@@ -1398,24 +1394,33 @@ int enqueue_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correct_dc,
     }
     if (correct_dc && !c->opt_dc_blocked) {
         Bracket b(c, c->stream, KIND_INGEST, 0);
-        hipLaunchKernelGGL(k_ingest_u8_dc, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(c->d_raw_u8),
+        hipLaunchKernelGGL(k_ingest_u8_dc, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(dev_bytes),
                            reinterpret_cast<float4 *>(c->d_raw_tiled), n_complex, c->d_dc_state);
         mode = kRawTiled;
     } else if (correct_dc) {
         Bracket b(c, c->stream, KIND_INGEST, 0);
         const int par = (int)(c->dc_frames++ & 1ull);
         double2 *sums = reinterpret_cast<double2 *>(c->d_dc_tab + c->dc_tab_sums);
-        hipLaunchKernelGGL(k_dc_block_sums, dim3(nchunks), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(c->d_raw_u8), n_complex,
+        hipLaunchKernelGGL(k_dc_block_sums, dim3(nchunks), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(dev_bytes), n_complex,
                            c->d_dc_tab, sums);
-        hipLaunchKernelGGL(k_ingest_u8_dc_fast, dim3(nchunks), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(c->d_raw_u8),
+        hipLaunchKernelGGL(k_ingest_u8_dc_fast, dim3(nchunks), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(dev_bytes),
                            reinterpret_cast<float4 *>(c->d_raw_tiled), n_complex, c->d_dc_state + 2 * par, c->d_dc_state + 2 * (par ^ 1),
                            c->d_dc_tab, sums);
         mode = kRawTiled;
     }
-    rc = c->opt_exact ? enqueue_frame<true>(c, c->d_raw_u8, mode, egress) : enqueue_frame<false>(c, c->d_raw_u8, mode, egress);
+    const int rc = c->opt_exact ? enqueue_frame<true>(c, dev_bytes, mode, egress) : enqueue_frame<false>(c, dev_bytes, mode, egress);
     if (rc == SDRX_OK)
         c->last_raw = mode;
     return rc;
+}
+
+int enqueue_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correct_dc, bool egress)
+{
+    int rc = ensure_raw(c, (size_t)c->root_frame);
+    if (rc)
+        return rc;
+    rc = stage_host_frame(c, bytes, (size_t)n_complex * 2, c->d_raw_u8);
+    return rc ? rc : enqueue_u8_device(c, c->d_raw_u8, n_complex, correct_dc, egress);
 }
 
 } // namespace
@@ -1549,6 +1554,8 @@ int sdrx_get_output(sdrx_ctx *c, int id, const void **buf, uint32_t *len, uint32
     const Node &n = c->nodes[(size_t)id];
     if (!n.leaf)
         return fail(c, SDRX_EINVAL, "vfo %d has children and publishes nothing (vfo.cpp:253-266)", id);
+    if (c->in_flight > 0 && c->host_slot < 0)
+        return fail(c, SDRX_ESTATE, "sdrx_get_output: %d submitted frame(s), none delivered yet -- call sdrx_wait first", c->in_flight);
     if (c->pending_fetch) { // frames queued with sdrx_process_device: bring the last one's payloads over
         int rc = sdrx_fetch(c);
         if (rc)
@@ -1572,6 +1579,8 @@ int sdrx_get_raw(sdrx_ctx *c, float *out, int max_complex, int *n_ret)
         return SDRX_EINVAL;
     if (!c->finalized || c->frame_no == 0)
         return fail(c, SDRX_ESTATE, "sdrx_get_raw: no frame processed yet");
+    if (c->in_flight > 0)
+        return fail(c, SDRX_ESTATE, "sdrx_get_raw: %d submitted frame(s) not yet delivered -- call sdrx_wait first", c->in_flight);
     if (c->last_raw < 0)
         return fail(c, SDRX_ESTATE, "sdrx_get_raw: the last frame was caller-owned device memory (sdrx_process_device)");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1607,6 +1616,8 @@ int sdrx_get_stream(sdrx_ctx *c, int id, float *out, int max_complex, int *n_ret
         return fail(c, SDRX_EINVAL, "bad vfo id %d", id);
     if (!c->finalized || c->frame_no == 0)
         return fail(c, SDRX_ESTATE, "sdrx_get_stream: no frame processed yet");
+    if (c->in_flight > 0) // the stream buffers already belong to the newest submitted frame, not to the last delivered one
+        return fail(c, SDRX_ESTATE, "sdrx_get_stream: %d submitted frame(s) not yet delivered -- call sdrx_wait first", c->in_flight);
     const Node &n = c->nodes[(size_t)id];
     const int par = (int)((c->frame_no - 1) & 1ull);
     const int cnt = std::min(max_complex, n.n_f);
@@ -1641,6 +1652,8 @@ int sdrx_get_prequant(sdrx_ctx *c, int id, float *out, int max, int *n_ret)
     const Node &n = c->nodes[(size_t)id];
     if (!c->finalized || !c->opt_prequant || !n.leaf || !n.d.demod_usb)
         return fail(c, SDRX_ESTATE, "sdrx_get_prequant: set option keep_prequant=1 before finalize; USB leaves only");
+    if (c->in_flight > 0)
+        return fail(c, SDRX_ESTATE, "sdrx_get_prequant: %d submitted frame(s) not yet delivered -- call sdrx_wait first", c->in_flight);
     const int cnt = std::min(max, n.n_out);
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = drain(c))

@@ -75,7 +75,7 @@ int member_fail(sdrx_group *g, int k, int rc)
 
 // frame (cf32 or bytes, `bytes` long) is complete on the first device at `src` once ev_ready[p] fires:
 // fan it out and enqueue frame processing on every member.
-int group_enqueue(sdrx_group *g, const void *src, size_t bytes, int raw_mode, bool egress)
+int group_enqueue(sdrx_group *g, const void *src, size_t bytes, int raw_mode, bool egress, int correct_dc = 0)
 {
     const int p = (int)(g->frame_no & 1ull);
     for (size_t k = 0; k < g->m.size(); ++k) {
@@ -93,7 +93,14 @@ int group_enqueue(sdrx_group *g, const void *src, size_t bytes, int raw_mode, bo
             raw = M.d_frame[p];
         }
         M.c->last_raw = -1;
-        const int rc = M.c->opt_exact ? enqueue_frame<true>(M.c, raw, raw_mode, egress) : enqueue_frame<false>(M.c, raw, raw_mode, egress);
+        int rc;
+        if (raw_mode == kRawU8 && correct_dc) {
+            // sdrj.cpp:271-286 on every member: identical bytes and identical (zero-started) accumulators keep the
+            // members' DC estimates identical, so no state ever has to travel between devices
+            rc = enqueue_u8_device(M.c, raw, g->root_frame, 1, egress); // (leaves last_raw = tile layout: sdrx_get_raw serves it)
+        } else {
+            rc = M.c->opt_exact ? enqueue_frame<true>(M.c, raw, raw_mode, egress) : enqueue_frame<false>(M.c, raw, raw_mode, egress);
+        }
         if (rc) {
             g->broken = true; // earlier members already run this frame
             return member_fail(g, (int)k, rc);
@@ -132,6 +139,40 @@ int group_stage(sdrx_group *g, const void *host, size_t bytes)
     GHIP(g, hipMemcpyAsync(g->d_stage[p], g->h_stage[p], bytes, hipMemcpyHostToDevice, g->stage_stream));
     GHIP(g, hipEventRecord(g->ev_ready[p], g->stage_stream));
     return SDRX_OK;
+}
+
+// undo a partly done sdrx_group_finalize: a retry (or the destroy) starts from nothing
+void group_drop_members(sdrx_group *g)
+{
+    for (GroupMember &M : g->m) {
+        (void)hipSetDevice(M.device);
+        if (M.c)
+            sdrx_destroy(M.c);
+        M.c = nullptr;
+        M.global_of.clear();
+        for (int p = 0; p < 2; ++p) {
+            if (M.d_frame[p])
+                (void)hipFree(M.d_frame[p]);
+            M.d_frame[p] = nullptr;
+        }
+    }
+    if (!g->m.empty())
+        (void)hipSetDevice(g->m[0].device);
+    for (int p = 0; p < 2; ++p) {
+        if (g->h_stage[p])
+            (void)hipHostFree(g->h_stage[p]);
+        if (g->d_stage[p])
+            (void)hipFree(g->d_stage[p]);
+        if (g->ev_ready[p])
+            (void)hipEventDestroy(g->ev_ready[p]);
+        g->h_stage[p] = g->d_stage[p] = nullptr;
+        g->ev_ready[p] = nullptr;
+    }
+    if (g->stage_stream)
+        (void)hipStreamDestroy(g->stage_stream);
+    g->stage_stream = nullptr;
+    g->where.clear();
+    g->publish_order.clear();
 }
 
 void group_publish(sdrx_group *g)
@@ -182,16 +223,24 @@ int sdrx_group_create(sdrx_group **out, const int *devices, int n_devices)
             continue;
         int can = 0;
         (void)hipDeviceCanAccessPeer(&can, devices[k], devices[0]);
-        if (!can) {
-            g->peer_ok = false;
-            continue;
+        hipError_t pe = hipSuccess;
+        if (can) {
+            (void)hipSetDevice(devices[k]);
+            pe = hipDeviceEnablePeerAccess(devices[0], 0);
+            (void)hipGetLastError();
         }
-        (void)hipSetDevice(devices[k]);
-        hipError_t pe = hipDeviceEnablePeerAccess(devices[0], 0);
-        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+        if (!can || (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)) {
+            // not an error -- hipMemcpyPeerAsync still works, staged through host memory by the runtime -- but the
+            // N-1 copies then no longer run on N-1 xGMI links at once: say so (sdrx_group_peer_access,
+            // sdrx_group_last_error right after the create)
             g->peer_ok = false;
-        (void)hipGetLastError();
+            char note[160];
+            snprintf(note, sizeof note, "warning: device %d has no peer access to device %d%s%s: the raw-frame fan-out to it is host-staged",
+                     devices[k], devices[0], can ? ": " : "", can ? hipGetErrorString(pe) : "");
+            g->err = note;
+        }
     }
+    (void)hipSetDevice(devices[0]);
     *out = g;
     return SDRX_OK;
 }
@@ -200,26 +249,7 @@ int sdrx_group_destroy(sdrx_group *g)
 {
     if (!g)
         return SDRX_EINVAL;
-    for (GroupMember &M : g->m) {
-        (void)hipSetDevice(M.device);
-        if (M.c)
-            sdrx_destroy(M.c);
-        for (int p = 0; p < 2; ++p)
-            if (M.d_frame[p])
-                (void)hipFree(M.d_frame[p]);
-    }
-    if (!g->m.empty())
-        (void)hipSetDevice(g->m[0].device);
-    for (int p = 0; p < 2; ++p) {
-        if (g->h_stage[p])
-            (void)hipHostFree(g->h_stage[p]);
-        if (g->d_stage[p])
-            (void)hipFree(g->d_stage[p]);
-        if (g->ev_ready[p])
-            (void)hipEventDestroy(g->ev_ready[p]);
-    }
-    if (g->stage_stream)
-        (void)hipStreamDestroy(g->stage_stream);
+    group_drop_members(g);
     delete g;
     return SDRX_OK;
 }
@@ -266,12 +296,25 @@ int sdrx_group_set_publish_callback(sdrx_group *g, sdrx_publish_fn fn, void *use
 // children, member k of W gets children [K k / W, K (k+1) / W) with their whole subtrees and -- only if
 // that block is not empty -- a replica of the parent; parent-less leaves are block-partitioned among
 // themselves.
+static int group_finalize_impl(sdrx_group *g);
+
 int sdrx_group_finalize(sdrx_group *g)
 {
     if (!g)
         return SDRX_EINVAL;
     if (g->finalized)
         return gfail(g, SDRX_ESTATE, "sdrx_group_finalize called twice");
+    const int rc = group_finalize_impl(g);
+    if (rc != SDRX_OK) { // nothing of a half-built group stays behind (the error text does)
+        const std::string why = g->err;
+        group_drop_members(g);
+        g->err = why;
+    }
+    return rc;
+}
+
+static int group_finalize_impl(sdrx_group *g)
+{
     const int N = (int)g->descs.size(), W = (int)g->m.size();
     if (N == 0)
         return gfail(g, SDRX_ESTATE, "sdrx_group_finalize: no VFOs");
@@ -283,10 +326,18 @@ int sdrx_group_finalize(sdrx_group *g)
         else
             roots.push_back(i);
     }
+    // every parent-less VFO consumes the same raw frame (sdrj.cpp:288-294): one samples_per_buffer for all of
+    // them, whichever member they land on -- the staging and peer buffers below are sized for it
     g->root_frame = g->descs[(size_t)roots[0]].samples_per_buffer;
-    for (int r : roots)
+    for (int r : roots) {
+        if (g->descs[(size_t)r].samples_per_buffer != g->root_frame)
+            return gfail(g, SDRX_EINVAL, "vfo %d: all parent-less VFOs must share samples_per_buffer (%d != %d)", r,
+                         g->descs[(size_t)r].samples_per_buffer, g->root_frame);
         if (children[(size_t)r].empty())
             flat.push_back(r);
+    }
+    if (g->root_frame <= 0)
+        return gfail(g, SDRX_EINVAL, "vfo %d: samples_per_buffer must be positive", roots[0]);
     g->where.assign((size_t)N, std::make_pair(-1, -1));
     for (int k = 0; k < W; ++k) {
         std::vector<char> keep((size_t)N, 0);
@@ -341,6 +392,8 @@ int sdrx_group_finalize(sdrx_group *g)
         }
         if ((rc = sdrx_finalize(M.c)) != SDRX_OK)
             return member_fail(g, k, rc);
+        if (M.c->root_frame != g->root_frame)
+            return gfail(g, SDRX_EINVAL, "member %d was initialised for frames of %d samples, the group for %d", k, M.c->root_frame, g->root_frame);
         if (k > 0)
             for (int p = 0; p < 2; ++p)
                 GHIP(g, hipMalloc(&M.d_frame[p], (size_t)g->root_frame * sizeof(float2)));
@@ -380,20 +433,31 @@ int sdrx_group_submit(sdrx_group *g, const float *iq, int n_complex)
 }
 
 // dongle bytes (jonti/sdr.cpp:43-49): a quarter of the bytes cross PCIe and xGMI; every device applies
-// the b - 127 LUT itself.  (The DC-bias IIR of sdrj.cpp:271-286 is a sequential recurrence over the raw
-// stream: a host that wants it feeds sdrx_group_submit with the corrected floats, as sdrj::demodData does.)
-int sdrx_group_submit_u8(sdrx_group *g, const uint8_t *bytes, int n_complex)
+// the b - 127 LUT itself and, with correct_dc, the DC-bias IIR of sdrj.cpp:271-286 with an accumulator of
+// its own (the recurrence is sequential over the raw stream, so each member runs it on the whole frame: same
+// bytes, same start state, same result on every device -- nothing but the bytes is exchanged).
+int sdrx_group_submit_u8(sdrx_group *g, const uint8_t *bytes, int n_complex, int correct_dc)
 {
     int rc = group_check(g, "sdrx_group_submit_u8", bytes, n_complex, false);
     if (rc)
         return rc;
-    for (GroupMember &M : g->m)
-        if (M.c && !M.c->root_direct)
-            return gfail(g, SDRX_EUNSUPPORTED, "sdrx_group_submit_u8: a wide level 0 (more than 4 parent-less VFOs) takes float frames");
     const size_t nb = (size_t)n_complex * 2;
     rc = group_stage(g, bytes, nb);
-    return rc ? rc : group_enqueue(g, g->d_stage[g->frame_no & 1ull], nb, kRawU8, true);
+    return rc ? rc : group_enqueue(g, g->d_stage[g->frame_no & 1ull], nb, kRawU8, true, correct_dc);
 }
+
+int sdrx_group_process_u8(sdrx_group *g, const uint8_t *bytes, int n_complex, int correct_dc)
+{
+    int rc = group_check(g, "sdrx_group_process_u8", bytes, n_complex, true);
+    if (rc)
+        return rc;
+    rc = sdrx_group_submit_u8(g, bytes, n_complex, correct_dc);
+    return rc ? rc : sdrx_group_wait(g);
+}
+
+// 1: every member reaches the first device's frame directly (same device, or peer access enabled: one xGMI
+// link per peer); 0: at least one peer copy is staged through host memory by the runtime.
+int sdrx_group_peer_access(const sdrx_group *g) { return g ? (g->peer_ok ? 1 : 0) : SDRX_EINVAL; }
 
 // `dev_iq`: n_complex cf32 on the FIRST device of the group, complete in the order of `producer_stream`
 // (a hipStream_t of that device; NULL: complete already) at the time of the call; it must stay untouched
@@ -472,8 +536,8 @@ int sdrx_group_get_output(sdrx_group *g, int id, const void **buf, uint32_t *len
         return gfail(g, SDRX_EINVAL, "bad vfo id %d", id);
     if (!g->finalized)
         return gfail(g, SDRX_ESTATE, "sdrx_group_get_output before sdrx_group_finalize");
-    if (g->in_flight > 0)
-        return gfail(g, SDRX_ESTATE, "sdrx_group_get_output: %d submitted frame(s) not yet delivered", g->in_flight);
+    // (with frames in flight this keeps serving the last DELIVERED frame, like sdrx_get_output: its payloads sit in
+    // the host slot the frame in flight does not write; before the first delivery the member says SDRX_ESTATE)
     const auto w = g->where[(size_t)id];
     if (w.first < 0)
         return gfail(g, SDRX_EINVAL, "vfo %d is held by no device", id);

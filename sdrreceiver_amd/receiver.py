@@ -258,9 +258,37 @@ class Group:
         iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
         self._chk(self.L.sdrx_group_submit(self.h, iq.ctypes.data, iq.size // 2))
 
-    def submit_u8(self, iq_bytes) -> None:
+    def submit_u8(self, iq_bytes, correct_dc: bool = False) -> None:
         b = np.ascontiguousarray(iq_bytes, dtype=np.uint8).reshape(-1)
-        self._chk(self.L.sdrx_group_submit_u8(self.h, b.ctypes.data, b.size // 2))
+        self._chk(self.L.sdrx_group_submit_u8(self.h, b.ctypes.data, b.size // 2, int(bool(correct_dc))))
+
+    def process_u8(self, iq_bytes, correct_dc: bool = False) -> None:
+        b = np.ascontiguousarray(iq_bytes, dtype=np.uint8).reshape(-1)
+        self.published.clear()
+        self._chk(self.L.sdrx_group_process_u8(self.h, b.ctypes.data, b.size // 2, int(bool(correct_dc))))
+
+    def peer_access(self) -> bool:
+        """True: every member reaches the first device's frame directly (same device or xGMI peer access)."""
+        return bool(self.L.sdrx_group_peer_access(self.h))
+
+    def member_context(self, k: int):
+        ctx, dev = C.c_void_p(), C.c_int()
+        self._chk(self.L.sdrx_group_member(self.h, k, C.byref(ctx), C.byref(dev)))
+        return ctx, dev.value
+
+    def stream(self, vid: int) -> np.ndarray:
+        """decimate[decimateCount] of VFO `vid` (an id of the whole tree) from the member that holds it."""
+        m, lid = self.locate(vid)
+        ctx, _ = self.member_context(m)
+        n = C.c_int()
+        rc = self.L.sdrx_get_stream(ctx, lid, None, 0, C.byref(n))
+        if rc != 0:
+            raise SdrxError(rc, self.L.sdrx_last_error(ctx).decode())
+        out = np.zeros(2 * max(n.value, 1), np.float32)
+        rc = self.L.sdrx_get_stream(ctx, lid, out.ctypes.data, n.value, C.byref(n))
+        if rc != 0:
+            raise SdrxError(rc, self.L.sdrx_last_error(ctx).decode())
+        return out[: 2 * n.value].view(np.complex64).copy()
 
     def submit_device(self, dev_ptr: int, n_complex: int, producer_stream: int | None = None) -> None:
         self._chk(self.L.sdrx_group_submit_device(self.h, C.c_void_p(dev_ptr), int(n_complex), C.c_void_p(producer_stream or 0)))

@@ -57,3 +57,29 @@ def test_two_ranks_config5_shaped_tree():
         ok, outs = _launch("config5-2048")
     assert ok, "\n".join(outs)
     assert "OK 2048 leaves over 2 ranks: [1024, 1024]" in outs[0], outs[0]
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """What the driver's SCALE run launches at N = 8 -- `python -m torch.distributed.run --nproc-per-node 8
+    bench.py --gpus 8` on the FULL config 5 (65 536 sub VFOs, 8 192 per rank, mains replicated, 4 frames
+    per broadcast) -- with all eight ranks on the one GPU of the test box (SDRX_BENCH_SHARE_GPU=1: gloo
+    instead of RCCL, numbers meaningless).  The shapes, the sharding, the broadcast batching, the strong /
+    weak bookkeeping and the JSON line are exactly those of the real run; only the transport differs."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SDRX_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "8", "--warmup", "2", "--reps", "2"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["steps"] == 8
+    assert out["config"]["sub_vfos_per_gpu"] == 8192 and out["config"]["vfos_total"] == 65536 + 2
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    w = out["weak_config3"]
+    assert "error" not in w and w["scaling"] == "weak" and w["sub_vfos_total"] == 8 * 1024 and w["value"] > 0

@@ -98,3 +98,93 @@ def test_sampled_parity_and_all_vfo_properties(n_subs):
     assert len(rx.published) == n_leaves
     assert all(p.count(0) == len(p) for _, _, p in rx.published)
     rx.close()
+
+
+def _frames(topo, n, seed=1):
+    lcg = synth.Lcg(seed)
+    return [synth.lcg_frame(topo.frame, lcg) + synth.tone_frame(topo.frame, topo.fs, [(-377000.0, 25.0), (251000.0, 11.0)], f * topo.frame)
+            for f in range(n)]
+
+
+def test_all_10240_vfos_of_the_north_star_workload_bit_exact():
+    """BASELINE.json's north-star size with the oracle on EVERY sub VFO, not a sample: 10 240 sub VFOs
+    under the two sdr_25E mains, 2 frames; payloads (int16 audio as published) and final cf32 streams
+    bit-identical to the plain-C oracle.  The oracle keeps a whole NCO table per VFO (oscillator.cpp:13-30:
+    1.5-3 MB each), so it runs the tree in batches of 1 024 sub VFOs on all host cores -- legal because a
+    VFO's output does not depend on its siblings (vfo.cpp:253-264)."""
+    from sdrreceiver_amd.receiver import Receiver
+    topo = tp.config3(10240)
+    frames = _frames(topo, 2)
+    rx = Receiver.from_topology(topo)
+    subs = [i for i in range(len(topo.vfos)) if topo.vfos[i].parent >= 0]
+    assert len(subs) == 10240
+    pay = [{}, {}]
+    stream_sha = [{}, {}]
+    for f, iq in enumerate(frames):
+        rx.process(iq)
+        assert len(rx.published) == 10240
+        for i in subs:
+            pay[f][i] = rx.output(i).tobytes()
+            stream_sha[f][i] = hashlib.sha256(rx.stream(i).tobytes()).digest()
+    rx.close()
+    import os
+    threads = max(1, len(os.sched_getaffinity(0)))
+    checked = 0
+    for b in range(0, len(subs), 1024):
+        batch = subs[b:b + 1024]
+        onodes, oroots = _oracle_subset(topo, batch)
+        for f, iq in enumerate(frames):
+            ob.process_roots(oroots, iq, threads=threads)
+            for k, i in enumerate(batch):
+                assert onodes[k].usb().tobytes() == pay[f][i], (f, i, "payload")
+                assert hashlib.sha256(onodes[k].stream().tobytes()).digest() == stream_sha[f][i], (f, i, "stream")
+                checked += 1
+        for r in oroots:
+            r.free()
+    assert checked == 2 * 10240
+
+
+def test_config5_in_its_sharded_form_eight_members_of_8192():
+    """BASELINE config 5 as `bench.py --gpus 8` and sdrx_group over 8 devices build it: the 65 536-sub
+    tree cut into EIGHT shards of 8 192 sub VFOs (mains replicated), here as eight members of one group on
+    the one GPU of the test box (sdrj.cpp:288-294 -> vfo.cpp:253-264, fanned out over devices).  One
+    synchronous frame + two pipelined ones; the sampled VFOs (incl. the first and last sub of every shard
+    block) against the oracle bit for bit, and ONE sha256 over all 65 536 payloads in the reference's
+    publish order equal to the single-context run's -- so no shard loses, repeats or reorders a leaf."""
+    from sdrreceiver_amd.receiver import Group, Receiver
+    topo = tp.config5(65536)
+    sample = _sample(topo, 64, seed=5)
+    onodes, oroots = _oracle_subset(topo, sample)
+    frames = _frames(topo, 3, seed=9)
+    want = []
+    rx = Receiver.from_topology(topo)
+    for iq in frames:
+        rx.process(iq)
+        want.append(_payload_digest(rx))
+    rx.close()
+    g = Group.from_topology(topo, [0] * 8)
+    st = g.member_stats()
+    assert [s["n_leaves"] for s in st] == [8192] * 8 and all(s["n_vfos"] == 8192 + 2 for s in st)
+    assert g.peer_access()
+    got = []
+
+    def check(f):
+        got.append(_payload_digest(g))
+        for k, i in enumerate(sample):
+            assert np.array_equal(g.output(i), onodes[k].usb()), (f, i, "payload")
+
+    g.process(frames[0])
+    ob.process_roots(oroots, frames[0], threads=8)
+    check(0)
+    g.submit(frames[1])
+    g.submit(frames[2])
+    for f in (1, 2):
+        g.wait()
+        ob.process_roots(oroots, frames[f], threads=8)
+        check(f)
+    for k, i in enumerate(sample):  # the last frame's final cf32 streams, from whichever member holds the VFO
+        assert np.array_equal(bits(g.stream(i)), bits(onodes[k].stream())), (i, "stream")
+    assert got == want and all(n == 65536 for _, n in got)
+    g.close()
+    for r in oroots:
+        r.free()

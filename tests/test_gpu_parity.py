@@ -328,9 +328,30 @@ def test_group_of_contexts_in_one_process(members, key):
     first member, payloads published in the reference's order over the WHOLE tree (main order x sub
     order, sdrj.cpp:288-294 / vfo.cpp:257-263) whichever member computed them.  Every message of every
     frame equals the oracle's; synchronous and pipelined (submit / wait) interface; byte input."""
+    _group_body([0] * members, key)
+
+
+def test_group_over_distinct_devices():
+    """The same, over DISTINCT device ordinals: runs by itself wherever the box has two or more GPUs (the
+    1-GPU test box skips it) -- the branches no same-device run reaches: hipMemcpyPeerAsync between two
+    devices, peer-access enabling, the cross-device hipStreamWaitEvent on the first device's frame event.
+    A host-staged fallback of the peer copies is not an error but must be visible (sdrx_group_peer_access)."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"{n} GPU(s) here: the distinct-device group needs >= 2")
+    for key in ("profile_25e", "config3-64"):
+        g = _group_body(list(range(min(n, 8))), key)
+        print(f"group over {min(n, 8)} devices, {key}: peer access {'direct' if g else 'HOST-STAGED'}")
+
+
+def _group_body(devices, key):
     from sdrreceiver_amd.receiver import Group, SdrxError
+    members = len(devices)
     topo = tp.config3(64) if key == "config3-64" else golden_topology(key)
-    g = Group.from_topology(topo, [0] * members)
+    g = Group.from_topology(topo, devices)
+    peer = g.peer_access()
+    assert peer or len(set(devices)) > 1  # members of ONE device always reach the frame directly
     nodes, roots = ob.build_tree("port", topo)
     order = topo.leaves_in_publish_order()
 
@@ -378,8 +399,8 @@ def test_group_of_contexts_in_one_process(members, key):
         ob.process_roots(roots, ob.u8_to_float(b))
         assert g.published == want()
     import torch  # frames that are already on the first device, queued without payload copies
-    dev = [torch.from_numpy(iq).cuda() for iq in frames[:3]]
-    torch.cuda.synchronize()
+    dev = [torch.from_numpy(iq).to(f"cuda:{devices[0]}") for iq in frames[:3]]
+    torch.cuda.synchronize(devices[0])
     for f, d in enumerate(dev):
         g.process_device(d.data_ptr(), topo.frame)
         ob.process_roots(roots, frames[f])
@@ -390,6 +411,96 @@ def test_group_of_contexts_in_one_process(members, key):
     st = g.member_stats()
     assert sum(s["n_leaves"] for s in st if s) == len(order)
     g.close()
+    return peer
+
+
+def test_group_dongle_bytes_with_dc_bias_removal():
+    """The shipped sdr_25E.ini sets correct_dc_bias=1 (sdrj.cpp:271-286): dongle bytes into a device list
+    with the DC-bias IIR on.  Every member runs the recurrence itself on the fanned-out BYTES with an
+    accumulator of its own; identical bytes and start state keep the members' estimates identical, so
+    every leaf of every member equals the oracle fed with the host-side LUT + sequential fp32 IIR -- 1
+    synchronous + 4 pipelined frames (the state carries across frames while two are in flight), then a
+    frame WITHOUT the correction (the accumulators keep their state, the frame is not touched)."""
+    from sdrreceiver_amd.receiver import Group
+    topo = tp.profile_25e()
+    g = Group.from_topology(topo, [0, 0, 0])
+    nodes, roots = ob.build_tree("port", topo)
+    order = topo.leaves_in_publish_order()
+    lcg = synth.Lcg(21)
+    frames = [np.clip(synth.lcg_frame_u8(topo.frame, lcg).astype(np.int32) + 9, 0, 255).astype(np.uint8) for _ in range(6)]  # a DC offset of ~9 LSB
+    state = np.zeros(2, np.float32)
+
+    def want(b, dc):
+        x = ob.u8_to_float(b)
+        if dc:
+            ob.dc_correct(x, state)
+        ob.process_roots(roots, x)
+        return [(topo.vfos[i].topic.encode()[:5].ljust(5, b"\0"), topo.vfos[i].output_rate, nodes[i].usb().tobytes()) for i in order]
+
+    g.process_u8(frames[0], correct_dc=True)
+    assert g.published == want(frames[0], True)
+    g.submit_u8(frames[1], correct_dc=True)
+    for f in range(2, 5):
+        g.submit_u8(frames[f], correct_dc=True)
+        g.wait()
+        assert g.published == want(frames[f - 1], True), f - 1
+    g.wait()
+    assert g.published == want(frames[4], True)
+    assert abs(float(state[0])) > 1e-3  # the estimate moved: the correction did something
+    g.process_u8(frames[5], correct_dc=False)
+    assert g.published == want(frames[5], False)
+    g.close()
+
+
+def test_group_wide_level0_takes_bytes_too():
+    """Parent-less leaves (the flat workloads; more than 4 of them: level 0 gets a layout pass) block-
+    partitioned over a group, fed with dongle bytes with and without the DC-bias removal."""
+    from sdrreceiver_amd.receiver import Group
+    topo = tp.config3_flat(12)
+    g = Group.from_topology(topo, [0, 0])
+    nodes, roots = ob.build_tree("port", topo)
+    order = topo.leaves_in_publish_order()
+    lcg = synth.Lcg(4)
+    state = np.zeros(2, np.float32)
+    for f, dc in enumerate((False, True, True)):
+        b = synth.lcg_frame_u8(topo.frame, lcg)
+        x = ob.u8_to_float(b)
+        if dc:
+            ob.dc_correct(x, state)
+        ob.process_roots(roots, x, threads=4)
+        g.process_u8(b, correct_dc=dc)
+        for i in order:
+            assert np.array_equal(g.output(i), nodes[i].usb()), (f, dc, i)
+    g.close()
+
+
+def test_group_refuses_mains_with_different_frames_and_leaves_nothing_behind():
+    """every parent-less VFO consumes the same raw frame (sdrj.cpp:288-294).  A tree whose
+    roots disagree on samples_per_buffer is refused by sdrx_group_finalize -- whichever member a root
+    lands on (a single context refuses it too) -- the failed finalize leaves no contexts or device
+    memory behind, and the group can still only be destroyed or, after the failure, not be used."""
+    import torch
+    from sdrreceiver_amd.receiver import Group, SdrxError
+    topo = tp.config3_flat(8)
+    topo.vfos[5].samples_per_buffer = topo.frame // 2  # lands on the second member
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        with pytest.raises(SdrxError) as e:
+            Group.from_topology(topo, [0, 0])
+        assert e.value.code == -1 and "samples_per_buffer" in str(e.value)
+    # a failure INSIDE a member's finalize (an audio filter the reference rejects, firfilter.cpp:122-134)
+    # after an earlier member was already built
+    t2 = tp.config3(16)
+    last = t2.leaves_in_publish_order()[-1]
+    t2.vfos[last].filter_bw = 40000
+    with pytest.raises(SdrxError) as e:
+        Group.from_topology(t2, [0, 0])
+    assert e.value.code == -3
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20), "a failed sdrx_group_finalize left device memory behind"
 
 
 def test_group_with_more_devices_than_sub_vfos():
