@@ -165,11 +165,14 @@ int dropin_run(const sdrx_vfo_desc *descs, int n, const char *addr, int frames, 
             m->process(samples);
         drain(300); // everything published for this frame (the first recv waits up to the timeout)
     }
+    // MainWindow's stop: a vfo owns its children (vfo.cpp:49-57).  Before the subscriber goes: an implementation that
+    // delivers a frame late (the adapter with SDRX_PIPELINE=1) hands over what it still owes when its tree is deleted;
+    // the reference publishes nothing here.
+    for (vfo *m : mains)
+        delete m;
     drain(1500); // messages still on their way when the last frame's drain gave up (a loaded host)
     zmq_close(sub);
     zmq_ctx_term(zctx);
-    for (vfo *m : mains)
-        delete m; // a vfo owns its children (vfo.cpp:49-57)
     if ((int)all.size() > cap)
         return -3;
     std::memcpy(out, all.data(), all.size());

@@ -24,6 +24,17 @@
 //
 // Device selection (environment, read when a tree is committed): SDRX_DEVICE=<ordinal> (default 0), or
 // SDRX_DEVICES=<a,b,...>: the tree sharded over several GPUs of the node (sdrx_group_*).
+//
+// One upload per frame: sdrj::demodData hands every main VFO the SAME `samples` (sdrj.cpp:288-294).  The root that
+// is called first in a round uploads the frame; a root of another tree on the same device that is then called with
+// the same buffer (same address and length, not yet served from this upload, and a spot check of 64 values spread
+// over the frame agrees) runs on the uploaded copy (sdrx_process_shared): one PCIe crossing per frame instead of
+// one per main VFO.  SDRX_SHARE_UPLOAD=0 switches it off.
+//
+// SDRX_PIPELINE=1: process() only SUBMITS its frame (sdrx_submit*) and delivers the PREVIOUS frame's payloads --
+// the frame's kernels and the payload copy of the one before run concurrently, 0.30 instead of 0.55 ms per frame
+// and main on BASELINE config 3 -- at the price of one frame (250 ms) of latency; the last frame is delivered when
+// the tree is deleted (MainWindow's stop).  While an fftData tap is selected anywhere, frames are delivered at once.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -48,15 +59,51 @@ struct Tree {
     std::vector<vfo *> nodes;  // by library id
     std::vector<vfo *> leaves; // in publish order
     size_t cursor = 0;         // next leaf the publish callback serves
-    ~Tree()
-    {
-        if (ctx)
-            sdrx_destroy(ctx);
-        if (grp)
-            sdrx_group_destroy(grp);
-    }
+    int device = 0;
+    bool pipelined = false;    // SDRX_PIPELINE=1
+    int in_flight = 0;         // frames submitted and not yet delivered
+    ~Tree();
     const char *error() const { return grp ? sdrx_group_last_error(grp) : sdrx_last_error(ctx); }
+    // deliver the oldest submitted frame: payloads -> transmit buffers -> ZmqPublisher, in the reference's order
+    void deliver_one()
+    {
+        cursor = 0;
+        if ((grp ? sdrx_group_wait(grp) : sdrx_wait(ctx)) != SDRX_OK)
+            qFatal("sdrx adapter: sdrx_wait: %s", error());
+        --in_flight;
+    }
 };
+
+// The host frame most recently uploaded to a device by one of the trees (see "One upload per frame" above).
+struct Upload {
+    Tree *owner = nullptr;
+    const void *ptr = nullptr;
+    size_t n = 0;
+    float probe[64];
+    std::vector<const Tree *> served; // trees that have run on this upload (the owner included)
+};
+std::unordered_map<int, Upload> &uploads()
+{
+    static std::unordered_map<int, Upload> u;
+    return u;
+}
+int g_fft_taps = 0; // VFOs anywhere in the process with an fftData tap selected (vfo::fftVFOSlot)
+void take_probe(const float *iq, size_t n_floats, float *probe)
+{
+    for (size_t k = 0; k < 64; ++k)
+        probe[k] = iq[k * (n_floats - 1) / 63];
+}
+
+Tree::~Tree()
+{
+    auto it = uploads().find(device);
+    if (it != uploads().end() && it->second.owner == this)
+        uploads().erase(it);
+    if (ctx)
+        sdrx_destroy(ctx);
+    if (grp)
+        sdrx_group_destroy(grp);
+}
 
 // What the adapter must remember per object and the unmodified header has no member for.
 struct NodeState {
@@ -116,9 +163,18 @@ vfo::vfo(QObject *parent) : QObject(parent)
 
 vfo::~vfo()
 {
+    {
+        // a root in pipelined mode still owes its subscribers the last frame(s): delivered now, while the leaves exist
+        auto it = side().find(this);
+        if (it != side().end() && it->second.tree && it->second.id == 0)
+            while (it->second.tree->in_flight > 0)
+                it->second.tree->deliver_one();
+    }
     if (mpVFOs) // a vfo owns its children (vfo.cpp:49-57)
         for (int a = 0; a < mpVFOs->length(); ++a)
             delete mpVFOs->at(a);
+    if (emitFFT)
+        --g_fft_taps;
     // the tree (context, device memory) goes when its last node does: the root is deleted last
     side().erase(this);
 }
@@ -145,7 +201,9 @@ void vfo::setFilter(bool filter, int bw)
 void vfo::setVFOs(QVector<vfo *> *pVFOs) { mpVFOs = pVFOs; }
 void vfo::fftVFOSlot(QString topic) // vfo.cpp:492-509
 {
+    const bool was = emitFFT;
     emitFFT = topic.compare(zmqTopic) == 0;
+    g_fft_taps += (emitFFT ? 1 : 0) - (was ? 1 : 0);
     FFTcount = 0;
 }
 
@@ -210,6 +268,8 @@ void vfo::process(const std::vector<cpx_typef> &samples)
         // first frame for this root: commit it and everything below it
         std::shared_ptr<Tree> T = std::make_shared<Tree>();
         const std::vector<int> devices = devices_from_env();
+        T->device = devices[0];
+        T->pipelined = std::getenv("SDRX_PIPELINE") && std::atoi(std::getenv("SDRX_PIPELINE")) != 0;
         if (devices.size() > 1) {
             if (sdrx_group_create(&T->grp, devices.data(), (int)devices.size()) != SDRX_OK)
                 qFatal("sdrx adapter: sdrx_group_create: %s", sdrx_group_last_error(nullptr));
@@ -283,8 +343,42 @@ void vfo::process(const std::vector<cpx_typef> &samples)
     Tree &T = *me.tree;
     T.cursor = 0;
     const float *iq = reinterpret_cast<const float *>(samples.data());
-    if ((T.grp ? sdrx_group_process(T.grp, iq, (int)samples.size()) : sdrx_process(T.ctx, iq, (int)samples.size())) != SDRX_OK)
-        qFatal("sdrx adapter: sdrx_process: %s", T.error());
+    const int n = (int)samples.size();
+    // (any tap anywhere makes EVERY tree deliver at once: the trees of one receiver stay in step with each other)
+    const bool want_fft = g_fft_taps > 0;
+    // who uploads: this tree, unless another tree on the device already holds exactly this frame
+    sdrx_ctx *shared_from = nullptr;
+    if (T.ctx && n > 0 && !(std::getenv("SDRX_SHARE_UPLOAD") && std::atoi(std::getenv("SDRX_SHARE_UPLOAD")) == 0)) {
+        Upload &U = uploads()[T.device];
+        float probe[64];
+        take_probe(iq, (size_t)2 * n, probe);
+        const bool same = U.owner && U.owner != &T && U.owner->ctx && U.ptr == iq && U.n == (size_t)n &&
+                          std::find(U.served.begin(), U.served.end(), &T) == U.served.end() &&
+                          std::memcmp(probe, U.probe, sizeof probe) == 0;
+        if (same) {
+            shared_from = U.owner->ctx;
+            U.served.push_back(&T);
+        } else {
+            U.owner = &T;
+            U.ptr = iq;
+            U.n = (size_t)n;
+            std::memcpy(U.probe, probe, sizeof probe);
+            U.served.assign(1, &T);
+        }
+    }
+    if (!T.pipelined) {
+        const int rc = T.grp ? sdrx_group_process(T.grp, iq, n) : shared_from ? sdrx_process_shared(T.ctx, shared_from) : sdrx_process(T.ctx, iq, n);
+        if (rc != SDRX_OK)
+            qFatal("sdrx adapter: sdrx_process: %s", T.error());
+    } else {
+        // submit(f); deliver f-1 -- or everything, while a spectrum tap wants this very frame's streams
+        const int rc = T.grp ? sdrx_group_submit(T.grp, iq, n) : shared_from ? sdrx_submit_shared(T.ctx, shared_from) : sdrx_submit(T.ctx, iq, n);
+        if (rc != SDRX_OK)
+            qFatal("sdrx adapter: sdrx_submit: %s", T.error());
+        ++T.in_flight;
+        while (T.in_flight > (want_fft ? 0 : 1))
+            T.deliver_one();
+    }
     for (vfo *v : T.nodes) // vfo.cpp:290-293
         if (v->emitFFT) {
             int n = 0, id = side()[v].id;

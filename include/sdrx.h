@@ -165,6 +165,14 @@ int sdrx_set_stream(sdrx_ctx *ctx, void *hip_stream);
 int sdrx_submit(sdrx_ctx *ctx, const float *iq, int n_complex);
 int sdrx_submit_u8(sdrx_ctx *ctx, const uint8_t *iq_bytes, int n_complex, int correct_dc);
 int sdrx_submit_device(sdrx_ctx *ctx, const void *dev_iq, int n_complex);
+/* Two contexts on ONE device fed the same raw frame -- sdrj::demodData hands every main VFO the same `samples`
+ * (sdrj.cpp:288-294), and a binding that keeps one context per main VFO (host/qt/vfo_adapter.cpp) would otherwise
+ * upload the frame once per main: run through `ctx` the frame `src` staged LAST (host floats or dongle bytes given
+ * to sdrx_process* / sdrx_submit* of `src`; not after a DC-bias removal on the device) without another
+ * host-to-device copy.  `ctx` waits for src's upload on the device.  src's frame buffers are per frame parity: the
+ * shared frame stays valid until `src` stages the frame after next -- wait for it on `ctx` before that. */
+int sdrx_submit_shared(sdrx_ctx *ctx, sdrx_ctx *src);
+int sdrx_process_shared(sdrx_ctx *ctx, sdrx_ctx *src); /* = sdrx_submit_shared + sdrx_wait */
 int sdrx_wait(sdrx_ctx *ctx);
 int sdrx_in_flight(sdrx_ctx *ctx); /* >= 0: frames submitted and not yet delivered; < 0: error */
 

@@ -71,6 +71,8 @@ SYMBOLS = {
     "sdrx_get_prequant": (_i, [_vp, _i, _vp, _i, C.POINTER(_i)]),
     "sdrx_get_taps": (_i, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "sdrx_get_nco": (_i, [_vp, _i, C.c_long, C.c_long, _vp]),
+    "sdrx_submit_shared": (_i, [_vp, _vp]),
+    "sdrx_process_shared": (_i, [_vp, _vp]),
     "sdrx_group_create": (_i, [C.POINTER(_vp), C.POINTER(_i), _i]),
     "sdrx_group_destroy": (_i, [_vp]),
     "sdrx_group_last_error": (C.c_char_p, [_vp]),

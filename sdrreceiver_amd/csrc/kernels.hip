@@ -88,6 +88,36 @@ __device__ __forceinline__ v4f gldv4(const float4 *p) { return *(const SDRX_AS1 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4u gldv4u(const v4u *p) { return *(const SDRX_AS1 v4u *)p; }
 __device__ __forceinline__ void gstv2(float2 *p, v2f v) { *(SDRX_AS1 v2f *)p = v; }
+// Experiment switch -DSDRX_NT=1 (profiles/README.md, round 3): the leaf streams -- written by the mix/decimate launch,
+// read exactly once by the demodulation ~40 us later -- with the non-temporal hint on both sides.
+#ifndef SDRX_NT
+#define SDRX_NT 0
+#endif
+__device__ __forceinline__ void gstv2_leaf(float2 *p, v2f v)
+{
+#if SDRX_NT
+    __builtin_nontemporal_store(v, (SDRX_AS1 v2f *)p);
+#else
+    *(SDRX_AS1 v2f *)p = v;
+#endif
+}
+__device__ __forceinline__ void gstv4_leaf(float4 *p, v4f v)
+{
+#if SDRX_NT
+    __builtin_nontemporal_store(v, (SDRX_AS1 v4f *)p);
+#else
+    *(SDRX_AS1 v4f *)p = v;
+#endif
+}
+__device__ __forceinline__ float2 gld2_once(const float2 *p)
+{
+#if SDRX_NT
+    const v2f v = __builtin_nontemporal_load((const SDRX_AS1 v2f *)p);
+#else
+    const v2f v = *(const SDRX_AS1 v2f *)p;
+#endif
+    return make_float2(v.x, v.y);
+}
 __device__ __forceinline__ void gstv4(float4 *p, v4f v) { *(SDRX_AS1 v4f *)p = v; }
 
 // ------------------------------------------------------------------------------------ NCO
@@ -413,11 +443,75 @@ __host__ __device__ constexpr int stage_offset(int s) // float2 index of A_s, s 
 }
 __host__ __device__ constexpr int pad0(int p) { return p + 2 * (p >> 4); }
 constexpr int kTransposeElems = kChunk + 2 * (kChunk >> 4); // 1152 float2
+// LDS-DMA prefetch of the input tiles (global_load_lds_dwordx4: HBM/L2 -> LDS with no VGPR in between, issued one
+// half-tile or one tile ahead of its use).  SDRX_GLDS = 0: off (8 plain 16-byte loads per lane at the top of every
+// chunk); 1: a 4 KiB slot = half a tile, refilled twice per chunk; 2: an 8 KiB slot = the whole next tile.
+#ifndef SDRX_GLDS
+#define SDRX_GLDS 0
+#endif
+constexpr int kGldsTileBytes = SDRX_GLDS == 1 ? 4096 : SDRX_GLDS == 2 ? 8192 : 0;
+constexpr int kGldsBytes = kGldsTileBytes + (SDRX_GLDS ? 512 : 0); // + the chunk's 64 NCO checkpoints as two planes of 64 floats
 __host__ __device__ constexpr int k1_lds_bytes(int d, bool need_transpose)
 {
     int stages = 8 * stage_offset(d < kRegStages ? kRegStages : d);
     int tr = need_transpose ? 8 * kTransposeElems : 0;
-    return kCarryBytes + (stages > tr ? stages : tr);
+    return kGldsBytes + kCarryBytes + (stages > tr ? stages : tr);
+}
+
+// N pieces of 1 KiB: piece k lands at LDS byte address lds_base + 1024 k + 16 lane (the instruction offset applies to
+// the global AND the LDS address; the destination is lane-linear = exactly the tile layout's [i2][lane] order) from
+// `src` + 1024 k bytes, a per-lane pointer.  Waits for the wave's earlier LDS reads first (the slot is being re-used).
+// The compiler does not know these loads: the data is ordered for a later ds_read only by glds_wait().
+template <int N>
+__device__ __forceinline__ void glds_issue(const float4 *src, unsigned lds_base)
+{
+    static_assert(N == 4 || N == 8, "half a tile or a tile");
+    unsigned keep;
+    if (N == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(lds_base)
+                     : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %2, off offset:2048\n\tglobal_load_lds_dwordx4 %2, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "v"(src + 256), "s"(lds_base), "s"(lds_base + 4096u)
+                     : "memory");
+}
+// every LDS-DMA (and every other vector memory operation) this wave has issued is complete
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// "These values exist NOW": an empty volatile asm that reads and writes them.  Volatile asms keep their order, so
+// everything the values depend on is computed -- and every load they come from waited for -- before the next
+// glds_wait() / glds_issue(); without it the optimiser sinks the arithmetic that is meant to cover a DMA's latency
+// below the wait, and parks its own vmcnt waits for the level-0 loads behind a join the tile path runs through too.
+__device__ __forceinline__ void pin(v2f &a) { asm volatile("" : "+v"(a)); }
+template <int N>
+__device__ __forceinline__ void pin_all(v2f *a)
+{
+#pragma unroll
+    for (int i = 0; i < N; i += 4)
+        asm volatile("" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]));
+}
+// One float2 per lane (the lane's NCO checkpoint; `src` per lane) as two planes: re at lds_base + 4 lane, im at
+// lds_base + 256 + 4 lane.  (The second piece reads src + 4 bytes through the instruction offset, which also moves
+// its LDS address by 4: hence M0 = base + 252.)
+__device__ __forceinline__ void glds_issue_cp(const float2 *src, unsigned lds_base)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+                 "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off offset:4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_base), "s"(lds_base + 252u)
+                 : "memory");
 }
 
 // k_mix_decimate is ONE wave per workgroup and every LDS byte it touches is private to that wave.
@@ -449,8 +543,12 @@ __device__ __forceinline__ void hb_stage_lds(v2f *__restrict__ A, v2f *__restric
         const v2f y = hb_dot2<EXACT>(w[0], w[2], w[4], w[5], w[6], w[8], w[10]);
         if (!last)
             B[kCarry + j] = y;
-        else if (j >= jmin) // outputs below jmin belong to the warm-up of a segment that starts inside the frame
-            gstv2(gout + (tiled ? tile_pos(gbase + j) : (size_t)(gbase + j)), y);
+        else if (j >= jmin) { // outputs below jmin belong to the warm-up of a segment that starts inside the frame
+            if (tiled)
+                gstv2(gout + tile_pos(gbase + j), y);
+            else
+                gstv2_leaf(gout + (size_t)(gbase + j), y);
+        }
     }
     wave_sync(); // all window reads done before the carry is overwritten
     // FIRQueueBackToFront (dsp.cpp:163-173) at the end of the FRAME: x[-k] := x[size-1-k]
@@ -489,6 +587,12 @@ template <bool EXACT>
 __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K1Work W, unsigned long long frame_no,
                                          const void *__restrict__ raw, int raw_mode, bool level0, unsigned char *smem, int lane)
 {
+#if SDRX_GLDS
+    const unsigned char *slot = smem; // the LDS-DMA landing area: (half) a tile, lane-linear like the tile itself ...
+    const float *cpl = reinterpret_cast<const float *>(smem + kGldsTileBytes); // ... and the chunk's checkpoints, [re 64 | im 64]
+    const unsigned slot_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem); // LDS byte address of `slot`
+    smem += kGldsBytes;
+#endif
     v2f *car0 = reinterpret_cast<v2f *>(smem);             // [8]
     v2f *car1 = car0 + 8;                                  // [8]
     v2f *lds = reinterpret_cast<v2f *>(smem + kCarryBytes);
@@ -531,6 +635,23 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
 #endif
     const int lane16 = (W.s_begin >> 4) + lane; // this lane's run in the item's first chunk, in units of 16 samples
     const float4 *src_item = in + tile_unit(lane16 >> 6, 0, lane16 & 63);
+#if SDRX_GLDS
+    // items fed from a tile-layout stream (every sub VFO; a wide level 0) take their tiles through the LDS-DMA slot
+    const bool tile_in = !(level0 && raw_mode != kRawTiled);
+    // this lane's NCO checkpoint for the chunk at `b`: cp[idx >> 4], idx = table position of the lane's first sample
+    auto cp_of = [&](int b) {
+        int ix = phase_frame + b; // both < L
+        ix -= ix >= D.L ? D.L : 0;
+        ix += lane * kRun;        // L >= kChunk (checked by sdrx_finalize)
+        ix -= ix >= D.L ? D.L : 0;
+        return D.cp + (ix >> 4);
+    };
+    if (tile_in) {
+        glds_issue<SDRX_GLDS == 1 ? 4 : 8>(src_item, slot_lds);
+        glds_issue_cp(cp_of(W.s_begin), slot_lds + kGldsTileBytes);
+        glds_wait();
+    }
+#endif
     for (int base = W.s_begin; base < W.s_end; base += kChunk) {
         const int valid = min(kChunk, D.n_in - base);
         const int p16 = (base >> 4) + lane;               // this lane's run, in units of 16 samples
@@ -539,6 +660,9 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         const bool save = base + valid == D.n_in;         // the chunk that holds the frame's last sample
         const int lv = (valid >> 4) - 1; // last lane holding real samples
         const bool active = lane <= lv;
+#if SDRX_GLDS
+        v2f o_lds = zero2;
+#endif
 
         // 1. this lane's run of 16 consecutive samples: 8 coalesced 16-byte loads
         v2f ext0[10 + kRun]; // ext0[10 + t] = x[t]; ext0[0..9] = halo x[-10..-1]
@@ -555,6 +679,9 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
                 x[2 * i] = lo2(v);
                 x[2 * i + 1] = hi2(v);
             }
+#if SDRX_GLDS
+            pin_all<16>(x);
+#endif
         } else if (level0 && raw_mode == kRawU8) {
             // dongle bytes: floats[b] = b - 127 (jonti/sdr.cpp:43-49), 32 bytes per lane
             const v4u *nat = reinterpret_cast<const v4u *>(raw) + (size_t)p16 * 2;
@@ -571,12 +698,16 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
                     x[8 * h + 2 * k + 1] = b;
                 }
             }
+#if SDRX_GLDS
+            pin_all<16>(x);
+#endif
         } else {
             // The lane's position inside its tile is the same in every chunk of the item (the walk
             // advances by exactly one tile per chunk): src_item is computed once, a chunk adds 512
             // units.  A shifted walk straddles two tiles; its idle lanes in the frame's last chunk may
             // read the (zero) tile behind the last one, which every tile-layout buffer has.
             const float4 *src = src_item + (size_t)((base - W.s_begin) >> 10) * 512;
+#if SDRX_GLDS == 0
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #ifndef SDRX_ABL_LOAD
@@ -588,6 +719,32 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
                 x[2 * i] = lo2(v);
                 x[2 * i + 1] = hi2(v);
             }
+#elif SDRX_GLDS == 1
+            // the first half of the tile landed in the slot during the previous chunk (and was waited for there);
+            // its second half is requested as soon as these reads are back, and used after 8 NCO / mix steps
+            const v4f *sl = reinterpret_cast<const v4f *>(slot) + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v4f v = sl[64 * i];
+                x[2 * i] = lo2(v);
+                x[2 * i + 1] = hi2(v);
+            }
+            o_lds = v2f{cpl[lane], cpl[64 + lane]};
+            glds_issue<4>(src + 256, slot_lds);
+#else
+            const v4f *sl = reinterpret_cast<const v4f *>(slot) + lane;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const v4f v = sl[64 * i];
+                x[2 * i] = lo2(v);
+                x[2 * i + 1] = hi2(v);
+            }
+            o_lds = v2f{cpl[lane], cpl[64 + lane]};
+            if (base + kChunk < W.s_end) { // the whole next tile and its checkpoints travel while this one is worked on
+                glds_issue<8>(src + 512, slot_lds);
+                glds_issue_cp(cp_of(base + kChunk), slot_lds + kGldsTileBytes);
+            }
+#endif
         }
 
         // 2. NCO: regenerate table[idx .. idx+16) from the checkpoint before it, and mix
@@ -597,18 +754,58 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         idx -= idx >= D.L ? D.L : 0;
         idx += lane * kRun;           // L >= kChunk (checked by sdrx_finalize)
         idx -= idx >= D.L ? D.L : 0;
+#if SDRX_GLDS
+        v2f o = o_lds;
+        if (!tile_in) {
+            o = gldv2(D.cp + (idx >> 4));
+            asm volatile("" : "+v"(o)); // the wait for this load stays inside the branch (at the join it would drain the DMA)
+        }
+#else
         v2f o = gldv2(D.cp + (idx >> 4));
+#endif
+#if !SDRX_GLDS
         const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
+#endif
 #pragma unroll
         for (int i = 0; i < kRun; ++i) {
+#if SDRX_GLDS == 1
+            if (i == kRun / 2) { // the 8 steps above are the latency cover of the DMA: they stay above
+                pin(o);
+                pin_all<8>(x);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (i == kRun / 2 && tile_in) {
+                // second half of the tile: requested at the top of the chunk, 8 NCO / mix steps ago
+                glds_wait();
+                const v4f *sl = reinterpret_cast<const v4f *>(slot) + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4f v = sl[64 * q];
+                    x[8 + 2 * q] = lo2(v);
+                    x[8 + 2 * q + 1] = hi2(v);
+                }
+                if (base + kChunk < W.s_end) { // first half of the NEXT tile + its checkpoints: used a whole chunk later
+                    glds_issue<4>(src_item + (size_t)(((base - W.s_begin) >> 10) + 1) * 512, slot_lds);
+                    glds_issue_cp(cp_of(base + kChunk), slot_lds + kGldsTileBytes);
+                }
+            }
+#endif
 #ifndef SDRX_ABL_NCO
             o = nco_step_pk(o, rot);
 #else
             asm volatile("" : "+v"(o)); // ablation: keep the value opaque, skip the recurrence
 #endif
             v2f m = o;
+#if SDRX_GLDS
+            if (i == 0 && frame_no == 0 && base == 0) { // (a scalar load: no vmcnt wait near the DMAs in flight)
+                const v2f last = {ldc(&D.cp[D.L >> 4].x), ldc(&D.cp[D.L >> 4].y)};
+                if (lane == 0)
+                    m = last;
+            }
+#else
             if (i == 0 && first_ever)
                 m = gldv2(D.cp + (D.L >> 4));
+#endif
 #ifndef SDRX_ABL_MIX
             x[i] = cmul(m, x[i]);
 #else
@@ -616,7 +813,26 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
 #endif
         }
 
+#if SDRX_GLDS
+        // The DMA for the next chunk was issued BEFORE this chunk's stores and is waited for before them too: at that
+        // point everything outstanding is old (the previous chunk's stores, a DMA that had the whole arithmetic of
+        // this chunk to land), and the stores themselves are never waited for (vmcnt counts loads and stores in order)
+#define GLDS_PRE_STORE()                                                                                  \
+    do {                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        if (tile_in)                                                                                      \
+            glds_wait();                                                                                  \
+    } while (0)
+#else
+#define GLDS_PRE_STORE() \
+    do {                 \
+    } while (0)
+#endif
         if (D.d == 0) {
+#if SDRX_GLDS
+            pin_all<16>(x);
+#endif
+            GLDS_PRE_STORE();
             // no decimation: decimate[0] is the mixed stream itself
             if (D.out_tiled) {
                 if (emit_l && active) {
@@ -688,6 +904,10 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
                 gstv2(hb_save + 0 * kHbHist + k - 1, x[15 - k]);
 
         if (D.d == 1) {
+#if SDRX_GLDS
+            pin_all<8>(y);
+#endif
+            GLDS_PRE_STORE();
             if (emit_l && active) {
                 const int g = (base >> 1) + lane * 8;
 #pragma unroll
@@ -748,12 +968,18 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
 #endif
 
         if (D.d == 2) {
+#if SDRX_GLDS
+            pin_all<4>(z);
+#endif
+            GLDS_PRE_STORE();
             if (emit_l && active) {
                 const int g = (base >> 2) + lane * 4;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const size_t pos = D.out_tiled ? tile_pos(g + 2 * i) : (size_t)(g + 2 * i);
-                    gstv4(reinterpret_cast<float4 *>(out + pos), cat2(z[2 * i], z[2 * i + 1]));
+                    if (D.out_tiled)
+                        gstv4(reinterpret_cast<float4 *>(out + tile_pos(g + 2 * i)), cat2(z[2 * i], z[2 * i + 1]));
+                    else
+                        gstv4_leaf(reinterpret_cast<float4 *>(out + (size_t)(g + 2 * i)), cat2(z[2 * i], z[2 * i + 1]));
                 }
             }
             continue;
@@ -770,10 +996,14 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
             gstv2(out + (base >> D.d) + lane, z[0] + z[1] + z[2] + z[3]);
         continue;
 #endif
-        for (int s = kRegStages; s < D.d; ++s)
+        for (int s = kRegStages; s < D.d; ++s) {
+            if (s + 1 == D.d)
+                GLDS_PRE_STORE();
             hb_stage_lds<EXACT>(lds + stage_offset(s), lds + stage_offset(s + 1), out, base >> D.d, D.out_tiled != 0, s + 1 == D.d,
                                 max(0, (first_out - base) >> D.d), valid >> s, lane, save, hb_save + s * kHbHist);
+        }
     }
+#undef GLDS_PRE_STORE
 }
 
 // One wave per workgroup, one workgroup per K1Work.  LEVEL only gives the root launch and the sub
@@ -1083,7 +1313,7 @@ __device__ __forceinline__ void demod_block(const K2Vfo *__restrict__ vfos, cons
 #pragma unroll
     for (int it = 0; it < kStageIters; ++it) {
         const int r = tid + 256 * it, idx = lo + r;
-        stage[it] = (r < nr && idx < D.n) ? gld2(z + idx) : make_float2(0.f, 0.f);
+        stage[it] = (r < nr && idx < D.n) ? gld2_once(z + idx) : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int it = 0; it < kStageIters; ++it) {

@@ -135,13 +135,16 @@ struct sdrx_ctx {
     size_t h_in_bytes = 0;
     int in_flight = 0;               // frames submitted (sdrx_submit*) and not yet delivered (sdrx_wait)
     int host_slot = -1;              // which h_pay holds the payloads sdrx_get_output serves
-    float2 *d_raw = nullptr;       // staging for host-fed frames (natural order)
+    float2 *d_raw[2] = {nullptr, nullptr}; // host-fed frames on the device (natural order), per frame parity: frame f's
+                                           //   buffer stays untouched until f+2 is staged (another context on this device may
+                                           //   be working on it: sdrx_submit_shared)
+    hipEvent_t ev_staged[2] = {nullptr, nullptr}; // the host frame of parity p is complete on the device
     float2 *d_raw_tiled = nullptr; // the raw frame in tile layout: input of the parent-less VFOs
     int last_raw = -1;             // how the last frame reached level 0 (kRaw*; -1: caller-owned device memory)
     bool late4 = false;            // k_late_decimate4 serves the late-decimation launch
     int late4_r = 4;               // outputs per lane of that kernel
     bool root_direct = false;      // level 0 reads the caller's natural-order frame itself (few VFOs)
-    unsigned char *d_raw_u8 = nullptr;
+    unsigned char *d_raw_u8[2] = {nullptr, nullptr}; // the same for dongle bytes
     float *d_dc_state = nullptr;   // DC-bias accumulator (exact: [2]; fast: [parity][2])
     double *d_dc_tab = nullptr;    // fast DC scan: powers of the decay + per-chunk sums behind them
     unsigned long long dc_frames = 0; // frames the fast scan has run on (its state ping-pongs)
@@ -520,8 +523,10 @@ void free_device_state(sdrx_ctx *c)
         hfree(c->h_in[p]);
     }
     c->h_in_bytes = 0;
-    dfree(c->d_raw);
-    dfree(c->d_raw_u8);
+    for (int p = 0; p < 2; ++p) {
+        dfree(c->d_raw[p]);
+        dfree(c->d_raw_u8[p]);
+    }
     dfree(c->d_raw_tiled);
     dfree(c->d_dc_state);
     dfree(c->d_dc_tab);
@@ -532,12 +537,16 @@ int ensure_raw(sdrx_ctx *c, size_t n_complex)
 {
     if (c->raw_cap >= n_complex)
         return SDRX_OK;
-    if (c->d_raw)
-        (void)hipFree(c->d_raw);
-    if (c->d_raw_u8)
-        (void)hipFree(c->d_raw_u8);
-    HIPCHK(c, hipMalloc(&c->d_raw, n_complex * sizeof(float2)));
-    HIPCHK(c, hipMalloc(&c->d_raw_u8, n_complex * 2));
+    for (int p = 0; p < 2; ++p) {
+        if (c->d_raw[p])
+            (void)hipFree(c->d_raw[p]);
+        if (c->d_raw_u8[p])
+            (void)hipFree(c->d_raw_u8[p]);
+        c->d_raw[p] = nullptr;
+        c->d_raw_u8[p] = nullptr;
+        HIPCHK(c, hipMalloc(&c->d_raw[p], n_complex * sizeof(float2)));
+        HIPCHK(c, hipMalloc(&c->d_raw_u8[p], n_complex * 2));
+    }
     c->raw_cap = n_complex;
     return SDRX_OK;
 }
@@ -586,7 +595,8 @@ int sdrx_create(sdrx_ctx **out, int device)
     for (int p = 0; p < 2 && ok; ++p)
         ok = hipEventCreateWithFlags(&c->ev_levels[p], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_tail[p], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&c->ev_copied[p], hipEventDisableTiming) == hipSuccess;
+             hipEventCreateWithFlags(&c->ev_copied[p], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_staged[p], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         sdrx_destroy(c);
         return fail(nullptr, SDRX_EHIP, "sdrx_create: could not create the streams / events of the context");
@@ -612,7 +622,7 @@ int sdrx_destroy(sdrx_ctx *c)
     for (hipEvent_t e : c->event_pool)
         (void)hipEventDestroy(e);
     for (int p = 0; p < 2; ++p)
-        for (hipEvent_t e : {c->ev_levels[p], c->ev_tail[p], c->ev_copied[p]})
+        for (hipEvent_t e : {c->ev_levels[p], c->ev_tail[p], c->ev_copied[p], c->ev_staged[p]})
             if (e)
                 (void)hipEventDestroy(e);
     free_device_state(c);
@@ -1351,6 +1361,7 @@ int stage_host_frame(sdrx_ctx *c, const void *src, size_t bytes, void *dst_dev)
     }
     memcpy(c->h_in[p], src, bytes);
     HIPCHK(c, hipMemcpyAsync(dst_dev, c->h_in[p], bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_staged[p], c->stream)); // (for a context that shares this frame: sdrx_submit_shared)
     return SDRX_OK;
 }
 
@@ -1359,10 +1370,11 @@ int enqueue_f32(sdrx_ctx *c, const float *iq, int n_complex, bool egress)
     int rc = ensure_raw(c, (size_t)c->root_frame);
     if (rc)
         return rc;
-    rc = stage_host_frame(c, iq, (size_t)n_complex * sizeof(float2), c->d_raw);
+    float2 *dst = c->d_raw[c->frame_no & 1ull];
+    rc = stage_host_frame(c, iq, (size_t)n_complex * sizeof(float2), dst);
     if (rc)
         return rc;
-    rc = c->opt_exact ? enqueue_frame<true>(c, c->d_raw, kRawF32, egress) : enqueue_frame<false>(c, c->d_raw, kRawF32, egress);
+    rc = c->opt_exact ? enqueue_frame<true>(c, dst, kRawF32, egress) : enqueue_frame<false>(c, dst, kRawF32, egress);
     if (rc == SDRX_OK)
         c->last_raw = kRawF32;
     return rc;
@@ -1419,8 +1431,9 @@ int enqueue_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correct_dc,
     int rc = ensure_raw(c, (size_t)c->root_frame);
     if (rc)
         return rc;
-    rc = stage_host_frame(c, bytes, (size_t)n_complex * 2, c->d_raw_u8);
-    return rc ? rc : enqueue_u8_device(c, c->d_raw_u8, n_complex, correct_dc, egress);
+    unsigned char *dst = c->d_raw_u8[c->frame_no & 1ull];
+    rc = stage_host_frame(c, bytes, (size_t)n_complex * 2, dst);
+    return rc ? rc : enqueue_u8_device(c, dst, n_complex, correct_dc, egress);
 }
 
 } // namespace
@@ -1455,6 +1468,39 @@ int sdrx_submit_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correct
 {
     int rc = check_frame_call(c, "sdrx_submit_u8", bytes, n_complex, false);
     return rc ? rc : enqueue_u8(c, bytes, n_complex, correct_dc, true);
+}
+
+// The frame `src` staged LAST (host floats or dongle bytes handed to sdrx_process* / sdrx_submit* of `src`) once
+// more, through the tree of `c` -- two contexts on one device fed the same raw frame, as sdrj::demodData feeds
+// every main VFO the same `samples` (sdrj.cpp:288-294) -- without a second host-to-device copy: `c` waits for
+// src's upload event and reads src's device buffer.  That buffer is per frame parity: it stays untouched until
+// `src` stages the frame after next, by which time the caller must have waited for this one on `c`.
+static int submit_shared(sdrx_ctx *c, sdrx_ctx *src, const char *what, bool sync_call)
+{
+    if (!c || !src || c == src)
+        return c ? fail(c, SDRX_EINVAL, "%s: needs another context as the source", what) : SDRX_EINVAL;
+    if (!src->finalized || src->frame_no == 0 || (src->last_raw != kRawF32 && src->last_raw != kRawU8))
+        return fail(c, SDRX_ESTATE, "%s: the source context has staged no host frame (floats or bytes without DC removal) yet", what);
+    if (src->device != c->device)
+        return fail(c, SDRX_EINVAL, "%s: the source context lives on device %d, this one on %d", what, src->device, c->device);
+    const int p = (int)((src->frame_no - 1) & 1ull);
+    const void *frame = src->last_raw == kRawF32 ? (const void *)src->d_raw[p] : (const void *)src->d_raw_u8[p];
+    int rc = check_frame_call(c, what, frame, src->root_frame, sync_call);
+    if (rc)
+        return rc;
+    if (src->last_raw == kRawU8 && !c->root_direct)
+        return fail(c, SDRX_EUNSUPPORTED, "%s: a wide level 0 (more than 4 parent-less VFOs) shares float frames only", what);
+    HIPCHK(c, hipStreamWaitEvent(c->stream, src->ev_staged[p], 0));
+    c->last_raw = -1; // (not this context's buffer: sdrx_get_raw is served by `src`)
+    return c->opt_exact ? enqueue_frame<true>(c, frame, src->last_raw, true) : enqueue_frame<false>(c, frame, src->last_raw, true);
+}
+
+int sdrx_submit_shared(sdrx_ctx *c, sdrx_ctx *src) { return submit_shared(c, src, "sdrx_submit_shared", false); }
+
+int sdrx_process_shared(sdrx_ctx *c, sdrx_ctx *src)
+{
+    const int rc = submit_shared(c, src, "sdrx_process_shared", true);
+    return rc ? rc : sdrx_wait(c);
 }
 
 int sdrx_in_flight(sdrx_ctx *c) { return c ? c->in_flight : SDRX_EINVAL; }
@@ -1588,10 +1634,10 @@ int sdrx_get_raw(sdrx_ctx *c, float *out, int max_complex, int *n_ret)
     if (int rc = drain(c))
         return rc;
     if (c->last_raw == kRawF32) {
-        HIPCHK(c, hipMemcpy(out, c->d_raw, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(out, c->d_raw[(c->frame_no - 1) & 1ull], (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
     } else if (c->last_raw == kRawU8) { // floats[b] = b - 127, jonti/sdr.cpp:43-49
         std::vector<uint8_t> b((size_t)n * 2);
-        HIPCHK(c, hipMemcpy(b.data(), c->d_raw_u8, b.size(), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(b.data(), c->d_raw_u8[(c->frame_no - 1) & 1ull], b.size(), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < b.size(); ++i)
             out[i] = (float)((int)b[i] - 127);
     } else { // tile layout (the DC-bias kernels wrote it): unit (chunk, i2, lane) = samples 16 lane + 2 i2, +1

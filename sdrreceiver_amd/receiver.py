@@ -128,6 +128,14 @@ class Receiver:
     def submit_device(self, dev_ptr: int, n_complex: int) -> None:
         self._chk(self.L.sdrx_submit_device(self.h, C.c_void_p(dev_ptr), int(n_complex)))
 
+    def process_shared(self, src: "Receiver") -> None:
+        """The frame `src` staged last (same device), once more through THIS tree, without a second upload."""
+        self.published.clear()
+        self._chk(self.L.sdrx_process_shared(self.h, src.h))
+
+    def submit_shared(self, src: "Receiver") -> None:
+        self._chk(self.L.sdrx_submit_shared(self.h, src.h))
+
     def wait(self) -> None:
         """Blocks until the oldest undelivered frame's payloads are on the host; `published` then
         holds that frame's messages and output() serves it."""

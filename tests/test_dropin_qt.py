@@ -109,3 +109,26 @@ def test_adapter_over_a_device_list():
     assert len(got) == len(want)
     for g, w in zip(got, want):
         assert g == w
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"SDRX_PIPELINE": "1"}, {"SDRX_SHARE_UPLOAD": "0"}, {"SDRX_PIPELINE": "1", "SDRX_SHARE_UPLOAD": "0"},
+                                 {"SDRX_PIPELINE": "1", "SDRX_DEVICES": "0,0"}])
+def test_adapter_modes_publish_the_same_bytes(env):
+    """The adapter's host-side modes change WHEN bytes move, never which: SDRX_PIPELINE=1 (process() submits its
+    frame and delivers the previous one -- sdrx_submit* / sdrx_wait -- the last frame at the tree's deletion),
+    with and without the shared upload (by default the second main VFO of a receiver runs on the frame the first
+    one uploaded: sdrx_process_shared / sdrx_submit_shared), and over a device list.  profile_25e has two main
+    VFOs and an fftData tap on one sub VFO: the subscriber's stream and the fftData log stay the reference's."""
+    got, want = _run("sdrx", "profile_25e", env=env)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g == w
+
+
+@pytest.mark.gpu
+def test_adapter_pipelined_two_receivers_and_stop_start():
+    got, want = _run("sdrx", "config4_12", copies=2, repeat=2, env={"SDRX_PIPELINE": "1"})
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g == w

@@ -1217,3 +1217,67 @@ def test_out_of_range_conversions_follow_the_x86_build(Receiver):
             seen_wrap |= bool((np.abs(pre) >= 2.0 ** 31).any()) and bool((np.abs(pre) > 40000).any())
     rx.close()
     assert seen_wrap, "the test signal must drive the audio beyond int32"
+
+
+def test_two_contexts_share_one_uploaded_frame(Receiver):
+    """sdrx_process_shared / sdrx_submit_shared: sdrj::demodData hands every main VFO the same `samples`
+    (sdrj.cpp:288-294); a binding that keeps one context per main VFO (host/qt/vfo_adapter.cpp) uploads the frame
+    through the first context and runs the second one on the uploaded copy.  The two mains of sdr_25E as two
+    contexts: synchronous, pipelined (the shared buffer is per frame parity: frame f stays valid while f+1 is
+    staged), from floats and from dongle bytes; every leaf bit-identical to the oracle running the whole tree."""
+    from sdrreceiver_amd.receiver import SdrxError
+    full = tp.profile_25e()
+    nodes, roots = ob.build_tree("port", full)
+    parts = []
+    for r in full.roots():
+        keep = [r] + full.children(r)
+        remap = {g: k for k, g in enumerate(keep)}
+        vf = [tp.VfoDesc(**{**full.vfos[g].__dict__, "parent": remap.get(full.vfos[g].parent, -1)}) for g in keep]
+        parts.append((keep, Receiver.from_topology(tp.Topology(fs=full.fs, frame=full.frame, vfos=vf))))
+    (k0, a), (k1, b) = parts
+    with pytest.raises(SdrxError) as e:
+        b.process_shared(a)  # nothing staged yet
+    assert e.value.code == -2
+
+    def check(rx, keep, f):
+        for local, g in enumerate(keep):
+            if full.vfos[g].parent >= 0:
+                assert np.array_equal(rx.output(local), nodes[g].usb()), (f, full.vfos[g].topic)
+
+    frames = [iq for _, iq in _frames(full, 7, seed=31, tones=[(-377000.0, 25.0)])]
+    for f in range(2):  # synchronous
+        a.process(frames[f])
+        b.process_shared(a)
+        ob.process_roots(roots, frames[f])
+        check(a, k0, f)
+        check(b, k1, f)
+    # pipelined: a.submit(f+1); a.wait() -> f; b.submit_shared(a) = f+1; b.wait() -> f
+    want = []
+    for f in range(2, 6):
+        ob.process_roots(roots, frames[f])
+        want.append({g: nodes[g].usb().copy() for g in k0 + k1 if full.vfos[g].parent >= 0})
+    a.submit(frames[2])
+    b.submit_shared(a)
+    for f in range(3, 6):
+        a.submit(frames[f])
+        a.wait()
+        b.submit_shared(a)
+        b.wait()
+        for rx, keep in ((a, k0), (b, k1)):
+            for local, g in enumerate(keep):
+                if full.vfos[g].parent >= 0:
+                    assert np.array_equal(rx.output(local), want[f - 3][g]), ("pipelined", f - 1, full.vfos[g].topic)
+    a.wait()
+    b.wait()
+    for rx, keep in ((a, k0), (b, k1)):
+        for local, g in enumerate(keep):
+            if full.vfos[g].parent >= 0:
+                assert np.array_equal(rx.output(local), want[3][g])
+    u8 = (frames[6] + 127).astype(np.uint8)  # dongle bytes: the LUT runs in each context's level 0
+    a.process_u8(u8)
+    b.process_shared(a)
+    ob.process_roots(roots, frames[6])
+    check(a, k0, 6)
+    check(b, k1, 6)
+    a.close()
+    b.close()

@@ -13,9 +13,11 @@ python3 bench.py $ARGS > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.
 rocprofv3 --kernel-trace --stats -d "$OUT" -o trace --output-format csv -- python3 bench.py $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
 # counter passes: one small group per run (SQ has 8 slots, TCC 4: FETCH_SIZE costs 3, WRITE_SIZE 2)
 i=0
-for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" \
-           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" \
-           "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM" "TCC_HIT_sum TCC_MISS_sum"; do
+# pass 3 is the VALU pass: instructions, dual-issue pairs, the cycle counter and the wait split of ONE pass
+# (tools/pmc_summary.py derives the calibrated valu_busy from it; tools/calib.sh runs the probe under the same set)
+for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU2 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" \
+           "SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" \
+           "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   rocprofv3 --pmc $PMC -d "$OUT" -o pmc$i --output-format csv -- python3 bench.py --steps 6 --warmup 2 --reps 1 --no-cpu --no-abi --no-side $* > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err" || echo "pmc pass $i failed: $PMC" >> "$OUT/errors.txt"
 done

@@ -9,6 +9,13 @@
 // SQ_INSTS_VALU* counters and the static ISA mix), and checks that THESE kernels read 1.00 +- 0.03
 // under the same formula -- including `mixlike`, whose instruction mix is that of the mix/decimate item.
 //
+// What the first run of this probe showed (MI355X, profiles/README.md "Round 3"): SQ_ACTIVE_INST_VALU is simply
+// SQ_INSTS_VALU (one quad-cycle per instruction, whatever the class), and the SIMD issues TWO plain two-VGPR-operand
+// fp32 instructions per quad-cycle when it can (SQ_ACTIVE_INST_VALU2 counts those quad-cycles; not with an SGPR
+// operand, not FMA, not packed).  So the VALU's busy quad-cycles are SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2, and the
+// elapsed cycles that belong next to them are SQ_BUSY_CYCLES / 32 SEs of the SAME pass (GRBM_GUI_ACTIVE / 8 also counts
+// ~8 us of dispatch overhead outside the kernel's own timestamps: +25 % on a 34 us kernel).
+//
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize valu_calib.hip -o valu_calib
 // Run:   ./valu_calib [waves_per_simd=5] [iters=3000]   (prints one JSON line per kernel: name, wave-instructions, ms)
 #include <hip/hip_runtime.h>
@@ -24,9 +31,9 @@ __device__ __forceinline__ float dpp_shr1(float old, float src)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x138, 0xf, 0xf, false));
 }
 
-enum { C_FMA32 = 0, C_MUL32, C_ADD32, C_MUL32_SGPR, C_PK_MUL, C_PK_ADD, C_PK_FMA, C_FMA64, C_CVT64, C_DPP, C_MIXLIKE, C_DEMODLIKE, C_HALF, N_CLASSES };
+enum { C_FMA32 = 0, C_MUL32, C_ADD32, C_MUL32_SGPR, C_PK_MUL, C_PK_ADD, C_PK_FMA, C_FMA64, C_CVT64, C_DPP, C_MIXLIKE, C_DEMODLIKE, C_ADD32_VV, N_CLASSES };
 static const char *kNames[N_CLASSES] = {"fma32", "mul32", "add32", "mul32_sgpr", "pk_mul", "pk_add", "pk_fma", "fma64", "cvt64", "dpp",
-                                        "mixlike", "demodlike", "half_duty"};
+                                        "mixlike", "demodlike", "add32_vv"};
 // VALU wave-instructions per loop iteration of each kernel (checked against the ISA: tools/calib.sh greps the .s)
 static const int kPerIter[N_CLASSES] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64};
 
@@ -34,7 +41,7 @@ template <int CLASS>
 __global__ __launch_bounds__(64) void k_calib(float *out, int iters, float a, float b, const float *__restrict__ taps)
 {
     float r = 0.f;
-    if constexpr (CLASS == C_FMA32 || CLASS == C_MUL32 || CLASS == C_ADD32 || CLASS == C_MUL32_SGPR || CLASS == C_DPP || CLASS == C_HALF) {
+    if constexpr (CLASS == C_FMA32 || CLASS == C_MUL32 || CLASS == C_ADD32 || CLASS == C_MUL32_SGPR || CLASS == C_DPP || CLASS == C_ADD32_VV) {
         float v[8];
         for (int i = 0; i < 8; ++i)
             v[i] = threadIdx.x * 0.001f + i;
@@ -46,8 +53,10 @@ __global__ __launch_bounds__(64) void k_calib(float *out, int iters, float a, fl
             for (int rr = 0; rr < 8; ++rr)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    if (CLASS == C_FMA32 || CLASS == C_HALF)
+                    if (CLASS == C_FMA32)
                         v[i] = __builtin_fmaf(v[i], a, b);
+                    else if (CLASS == C_ADD32_VV) // both operands VGPRs: the form the SIMD issues two of per quad-cycle
+                        v[i] = v[i] + v[(i + 3) & 7];
                     else if (CLASS == C_MUL32)
                         v[i] = v[i] * a;
                     else if (CLASS == C_ADD32)
@@ -57,8 +66,6 @@ __global__ __launch_bounds__(64) void k_calib(float *out, int iters, float a, fl
                     else
                         v[i] = dpp_shr1(v[i], v[(i + 1) & 7]);
                 }
-            if (CLASS == C_HALF) // ~as long idle as busy: 64 fmas at ~4 cycles vs s_sleep 4 = 4 * 64 cycles
-                __builtin_amdgcn_s_sleep(4);
         }
         for (int i = 0; i < 8; ++i)
             r += v[i];
@@ -221,7 +228,7 @@ int main(int argc, char **argv)
     run<C_DPP>(W, iters, d, taps, n_simd);
     run<C_MIXLIKE>(W, iters, d, taps, n_simd);
     run<C_DEMODLIKE>(W, iters, d, taps, n_simd);
-    run<C_HALF>(W, iters, d, taps, n_simd);
+    run<C_ADD32_VV>(W, iters, d, taps, n_simd);
     hipFree(d);
     hipFree(taps);
     return 0;
