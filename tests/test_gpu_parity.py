@@ -1273,10 +1273,10 @@ def test_two_contexts_share_one_uploaded_frame(Receiver):
         for local, g in enumerate(keep):
             if full.vfos[g].parent >= 0:
                 assert np.array_equal(rx.output(local), want[3][g])
-    u8 = (frames[6] + 127).astype(np.uint8)  # dongle bytes: the LUT runs in each context's level 0
+    u8 = np.clip(np.rint(frames[6]) + 127, 0, 255).astype(np.uint8)  # dongle bytes: the LUT runs in each context's level 0
     a.process_u8(u8)
     b.process_shared(a)
-    ob.process_roots(roots, frames[6])
+    ob.process_roots(roots, ob.u8_to_float(u8))
     check(a, k0, 6)
     check(b, k1, 6)
     a.close()
