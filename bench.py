@@ -231,29 +231,30 @@ def main():
     from sdrreceiver_amd import distributed as D, synth, topology as tp
     from sdrreceiver_amd.receiver import Receiver
     dist = None
-    if world > 1:
+    use_dist = world > 1 or D.force_collectives()  # (SDRX_FORCE_COLLECTIVES=1: the RCCL path with one rank, on a 1-GPU box)
+    if use_dist:
         import torch.distributed as dist
         D.init_process_group("gloo" if share else "nccl", device=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     stream = torch.cuda.Stream()  # a real (non-null) stream shared by torch, RCCL ordering and our kernels
     torch.cuda.set_stream(stream)
-    batch = args.batch or (4 if world > 1 else 1)
+    batch = args.batch or (4 if use_dist else 1)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def allmax(x):
-        if world == 1:
+        if not use_dist:
             return x
         t = torch.tensor([x], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def allsum(vals):
-        if world == 1:
+        if not use_dist:
             return [float(v) for v in vals]
         t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -481,6 +482,22 @@ def main():
         for key, name in (("north_star_10k", "10k"), ("flat_1024", "flat"), ("config4_256", "config4")):
             side[key] = side_reading(name)
 
+    # fourth (N = 1): the Qt drop-in -- `class vfo` of the reference's unmodified vfo.h over the adapter
+    # (host/qt/vfo_adapter.cpp), driven like sdrj::demodData drives it, transmitData / ZmqPublisher::publish included
+    if abi is not None and workload == "config3" and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdropin_sdrx.so")):
+        import subprocess
+        qt = {}
+        for label, env in (("sync", {}), ("sync_one_upload_per_main", {"SDRX_SHARE_UPLOAD": "0"}), ("pipelined", {"SDRX_PIPELINE": "1"})):
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dropin_run.py"), "time", "sdrx", "1024", "12"],
+                                   capture_output=True, text=True, timeout=300, env=dict(os.environ, SDRX_DEVICE=str(local), **env))
+                qt[label + "_ms"] = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_frame"] if r.returncode == 0 else {"error": r.stderr[-300:]}
+            except Exception as e:
+                qt[label + "_ms"] = {"error": f"{type(e).__name__}: {e}"}
+        qt["note"] = ("per frame: process() on both main VFOs of config 3 through the public interface of vfo.h, 1024 x (payload copy into "
+                      "transmit_usb + ZmqPublisher::publish) included; one context per main VFO")
+        abi["qt_adapter"] = qt
+
     weak = None
     if world > 1 and workload == "config5":
         # side reading: the weak-scaled config-3 workload (1 024 sub VFOs per GPU), the N = 1 BENCH workload
@@ -510,7 +527,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": descr, "name": full.name, "vfos_total": int(len(full.vfos)), "sub_vfos_per_gpu": int(st["n_leaves"]),
                        "frame_cf32": full.frame, "fs": full.fs, "arithmetic": "fast-fma" if args.fast else "exact (bit-identical to -O2 reference)",
-                       "parallelism": (f"vfo-shard x{world}, raw frames RCCL broadcast ({batch} per collective)" if world > 1 else "single GPU"),
+                       "parallelism": (f"vfo-shard x{world}, raw frames RCCL broadcast ({batch} per collective)" if use_dist else "single GPU"),
                        "launches": ("separate kernels, leaf tail of frame f beside the levels of frame f+1 (2 HIP streams)" if args.pipeline
                                     else "one kernel launch per tree level + leaf tail" if args.no_fuse
                                     else "k_mix_levels, one level per launch + leaf tail" if args.no_frame_pipeline
@@ -569,7 +586,7 @@ def main():
         print(json.dumps(out))
     if job:
         job.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

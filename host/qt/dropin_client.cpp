@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include <time.h>
 #include <unistd.h>
 
 #include "vfo.h"
@@ -182,6 +183,65 @@ int dropin_run(const sdrx_vfo_desc *descs, int n, const char *addr, int frames, 
         fft_out[k] = 0;
     }
     return (int)all.size();
+}
+
+// Wall time per frame of the loop `for every main VFO: process(samples)` (sdrj.cpp:288-294) through the public
+// interface of vfo.h -- setters, init, setVFOs, process -- with whatever implementation of `class vfo` is linked
+// behind it: what a Qt host pays per frame, transmitData / ZmqPublisher::publish of every leaf included (a PUB
+// socket without subscribers drops the messages in libzmq).  `warm` untimed frames, then `frames` timed ones.
+// Returns milliseconds per frame, < 0 on error.
+double dropin_time(const sdrx_vfo_desc *descs, int n, const char *addr, int warm, int frames)
+{
+    std::vector<vfo *> nodes((size_t)n);
+    std::vector<QVector<vfo *> *> kids((size_t)n, nullptr);
+    QVector<vfo *> mains;
+    int root_frame = 0;
+    for (int i = 0; i < n; ++i) {
+        const sdrx_vfo_desc &d = descs[i];
+        vfo *v = new vfo();
+        v->setZmqAddress(QString::fromUtf8(addr));
+        v->setZmqTopic(QString::fromLatin1(d.topic));
+        v->setFs(d.fs);
+        v->setDecimationCount(d.decimate_count);
+        v->setMixerFreq(d.mixer_freq_hz);
+        v->setDemodUSB(d.demod_usb != 0);
+        v->setFilterBandwidth(d.filter_bw_hz);
+        v->setGain(d.gain);
+        v->setCompressonStyle(d.cstyle);
+        v->setScaleComp(d.scalecomp);
+        v->init(d.samples_per_buffer, true, d.late_decimate);
+        nodes[(size_t)i] = v;
+        if (d.parent_id < 0) {
+            mains.append(v);
+            root_frame = d.samples_per_buffer;
+        } else {
+            if (!kids[(size_t)d.parent_id])
+                kids[(size_t)d.parent_id] = new QVector<vfo *>();
+            kids[(size_t)d.parent_id]->append(v);
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        if (kids[(size_t)i])
+            nodes[(size_t)i]->setVFOs(kids[(size_t)i]);
+    std::vector<cpx_typef> samples((size_t)root_frame);
+    uint32_t x = 1;
+    for (auto &s : samples) {
+        x = x * 1664525u + 1013904223u;
+        const float re = (float)((int)((x >> 24) % 17u) - 8);
+        x = x * 1664525u + 1013904223u;
+        s = cpx_typef(re, (float)((int)((x >> 24) % 17u) - 8));
+    }
+    struct timespec t0, t1;
+    for (int f = 0; f < warm + frames; ++f) {
+        if (f == warm)
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (vfo *m : mains)
+            m->process(samples);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (vfo *m : mains)
+        delete m;
+    return ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6) / (frames > 0 ? frames : 1);
 }
 
 // Does vfo::init throw for this description, and what?  Returns 1 and the exception's what() text where

@@ -24,10 +24,17 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def force_collectives() -> bool:
+    """SDRX_FORCE_COLLECTIVES=1: run the collective code path even in a 1-rank job -- on a 1-GPU box this is the
+    only way the RCCL ("nccl") branch, its communication stream and its events ever execute (the broadcast then
+    has one participant; transport over xGMI is of course not exercised)."""
+    return os.environ.get("SDRX_FORCE_COLLECTIVES") == "1"
+
+
 def init_process_group(backend: str | None = None, device: torch.device | None = None) -> tuple[int, int]:
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun's env)."""
     rank, world, _ = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
@@ -63,7 +70,8 @@ class FrameBroadcast:
         self.buf = [torch.empty(self.frames_per_batch * 2 * n_complex, dtype=torch.float32, device=device) for _ in range(2)]
         self.k = 0
         self.cuda = device.type == "cuda"
-        self.comm = torch.cuda.Stream(device) if (self.cuda and self.world > 1) else None
+        self.single = self.world == 1 and not (force_collectives() and dist.is_initialized())  # nothing to exchange
+        self.comm = torch.cuda.Stream(device) if (self.cuda and not self.single) else None
         self._pending = None            # (buffer, work handle or None)
         self._free = [None, None]       # per buffer: event after which it may be overwritten
         self._last = None               # index of the buffer handed out by the last result()
@@ -75,7 +83,7 @@ class FrameBroadcast:
     def __call__(self, frame: torch.Tensor | None) -> torch.Tensor:
         """`frame`: the new batch on the source rank (ignored elsewhere).  Returns this
         rank's copy, valid until the call after next."""
-        if self.world == 1:
+        if self.single:
             return frame
         b = self.buf[self.k & 1]
         self.k += 1
@@ -86,7 +94,7 @@ class FrameBroadcast:
 
     # -- overlapped form ------------------------------------------------------------------------
     def submit(self, frame: torch.Tensor | None) -> None:
-        if self.world == 1:
+        if self.single:
             self._pending = (frame, None)
             return
         i = self.k & 1
@@ -115,7 +123,7 @@ class FrameBroadcast:
 
     def result(self) -> torch.Tensor:
         assert self._pending is not None, "result() without submit()"
-        if self.world == 1:
+        if self.single:
             b, _ = self._pending
             self._pending = None
             return b
@@ -128,7 +136,7 @@ class FrameBroadcast:
     def consumed(self) -> None:
         """Marks, in the current stream's order, the point after which the buffer returned by the last
         result() may be overwritten (submit() does the same)."""
-        if self.world == 1 or not self.cuda or self._last is None:
+        if self.single or not self.cuda or self._last is None:
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())

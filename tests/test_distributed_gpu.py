@@ -83,3 +83,27 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     assert out["value"] > 0 and out["ms_per_step"] > 0
     w = out["weak_config3"]
     assert "error" not in w and w["scaling"] == "weak" and w["sub_vfos_total"] == 8 * 1024 and w["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_rccl_branch_with_one_rank():
+    """The "nccl" (= RCCL) branch of bench.py and distributed.FrameBroadcast -- process-group init with device_id,
+    the communication stream, the per-batch events, work.wait() on the compute stream, the all-reduces of the
+    timing -- cannot run with two ranks on the one GPU of the test box (RCCL refuses two ranks per device), so it
+    runs with ONE: SDRX_FORCE_COLLECTIVES=1 keeps every collective in the path.  What it cannot show is xGMI
+    transport; what it does show is that the first real N > 1 run does not die in RCCL set-up or stream plumbing."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SDRX_FORCE_COLLECTIVES="1")
+    env.pop("SDRX_BENCH_SHARE_GPU", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2", "--reps", "3",
+           "--no-cpu", "--no-abi", "--no-side"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and "RCCL broadcast (4 per collective)" in out["config"]["parallelism"]
+    assert out["value"] > 0 and out["config"]["sub_vfos_per_gpu"] == 1024
+    assert "overlapped broadcast unavailable" not in r.stderr

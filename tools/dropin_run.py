@@ -69,9 +69,31 @@ def probe(kind):
         pass
 
 
+def timing(kind, n_subs, frames):
+    """tools/dropin_run.py time <ref|sdrx> <n_subs> <frames>: milliseconds per frame of the demodData loop over the
+    main VFOs through the public interface of vfo.h (config-3 tree with n_subs sub VFOs), as JSON."""
+    C.CDLL("libstdc++.so.6", mode=C.RTLD_GLOBAL)
+    from sdrreceiver_amd import topology as tp
+    from sdrreceiver_amd._lib import VfoDescC, desc_to_c
+    topo = tp.config3(n_subs)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", f"libdropin_{kind}.so"))
+    lib.dropin_time.restype = C.c_double
+    descs = (VfoDescC * len(topo.vfos))(*[desc_to_c(d) for d in topo.vfos])
+    addr = f"ipc:///tmp/sdrx_dropin_time_{os.getpid()}".encode()
+    ms = lib.dropin_time(descs, len(topo.vfos), addr, 3, frames)
+    print(json.dumps({"kind": kind, "sub_vfos": n_subs, "frames": frames, "ms_per_frame": round(ms, 4),
+                      "mode": {k: os.environ[k] for k in ("SDRX_PIPELINE", "SDRX_SHARE_UPLOAD", "SDRX_DEVICES") if k in os.environ}}))
+    try:
+        os.unlink(addr.decode()[len("ipc://"):])
+    except OSError:
+        pass
+
+
 def main():
     if sys.argv[1] == "probe":
         return probe(sys.argv[2])
+    if sys.argv[1] == "time":
+        return timing(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
     kind, name, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
     fft_topic = sys.argv[4] if len(sys.argv) > 4 else ""
     copies = int(sys.argv[5]) if len(sys.argv) > 5 else 1
