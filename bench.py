@@ -164,7 +164,7 @@ def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix
         # cycles = SQ_BUSY_CYCLES / 32 of the SAME pass, normalised by what a saturated probe of the kernel's own
         # instruction mix reads under the same counters (tools/valu_calib.hip, profiles/valu_calibration.json)
         valu = {kk: v[kk] for kk in ("valu_busy", "valu_busy_raw", "calibration_probe", "probe_reads_raw", "dual_issued_frac", "valu_insts",
-                                     "cycles", "clock_GHz", "pass_dur_us", "resident_waves_per_simd", "wave_cycles_split", "lds_inst_busy")
+                                     "cycles", "clock_GHz", "pass_dur_us", "wave_cycles_split", "lds_inst_busy")
                 if kk in v}
         if mix_chunks and dom.startswith("k_mix"):
             valu["insts_per_1024_sample_chunk"] = round(v["valu_insts"] / mix_chunks, 1)

@@ -249,61 +249,110 @@ __global__ __launch_bounds__(256) void k_ingest_u8(const unsigned *__restrict__ 
 // The same with the DC-bias removal of sdrj::demodData (sdrj.cpp:271-286):
 //   avept = avept*(1.0f-0.000001f) + 0.000001f*curr;  curr -= avept        (per component, fp32)
 // with an accumulator that lives for the whole process (function-static there; `state` here).
-// It is a true first-order recurrence in ROUNDED fp32 arithmetic, so the bit-exact form is
-// sequential: ONE wave walks the frame in 1024-sample chunks, lanes 0 and 1 run the I and the Q
-// recurrence out of LDS (2 dependent VALU ops per sample), then all 64 lanes subtract and store the
-// chunk in tile layout.  ~10 cycles per sample: ~1.7 ms for a 384 000-sample frame -- far inside the
-// 250 ms frame period, and the only serial piece of the whole pipeline.
-__global__ __launch_bounds__(64) void k_ingest_u8_dc(const unsigned *__restrict__ bytes4, float4 *__restrict__ tiled, int n_complex,
-                                                     float *__restrict__ state)
+// It is a true first-order recurrence in ROUNDED fp32 arithmetic -- fl(fl(avept*keep) + fl(k*curr)) -- so the
+// bit-exact form is sequential in the frame.  What IS sequential is two dependent VALU operations per sample and
+// component; everything else is not, and is kept off that chain: one workgroup of four waves walks the frame in
+// 1024-sample chunks as a three-stage pipeline over the chunks,
+//   waves 2-3  prepare chunk c+1: bytes -> floats -> fl(k*curr) for both components, into LDS;
+//   wave 0 / 1 run the I / the Q recurrence of chunk c: per 4 samples one broadcast ds_read_b128 of the prepared
+//              products, 4 x (v_mul, v_add) on a wave-uniform accumulator, one ds_write_b128 of the 4 estimates;
+//   waves 2-3  finish chunk c-1: curr - avept, stored in tile layout.
+// One __syncthreads() per chunk.  Measured: 9.8 ms per 384 000-sample frame for the one-wave version of rounds 1-2
+// (whose "1.7 ms" was an estimate), see profiles/README.md for this one.
+__global__ __launch_bounds__(256) void k_ingest_u8_dc(const unsigned *__restrict__ bytes4, float4 *__restrict__ tiled, int n_complex,
+                                                      float *__restrict__ state)
 {
-    __shared__ __attribute__((aligned(16))) unsigned sB[kChunk / 2]; // 1024 samples = 2048 bytes
-    __shared__ __attribute__((aligned(16))) float sA[2][kChunk];     // avept after each sample, per component
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float sK[2][2][kChunk]; // fl(k * curr): [chunk parity][component][sample]
+    __shared__ __attribute__((aligned(16))) float sA[2][2][kChunk]; // avept after each sample
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float keep = 1.0f - 0.000001f, k = 0.000001f;
-    float acc = lane < 2 ? state[lane] : 0.f;
     const int nchunks = (n_complex + kChunk - 1) / kChunk;
-    for (int c = 0; c < nchunks; ++c) {
-        const int base = c * kChunk;
-        const int valid = min(kChunk, n_complex - base);
-        __syncthreads();
-        for (int i = lane; i < kChunk / 2; i += 64)
-            sB[i] = (2 * i < valid) ? bytes4[(base >> 1) + i] : 0x7f7f7f7fu;
-        __syncthreads();
-        if (lane < 2) {
-            const int sh = 8 * lane; // byte lane: I = byte 0 / 2, Q = byte 1 / 3 of each word
-            for (int i = 0; i < valid; i += 8) {
-                const uint4 w = *reinterpret_cast<const uint4 *>(sB + (i >> 1));
-                const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+    float acc = wave < 2 ? state[wave] : 0.f; // wave-uniform: every lane of a chain wave carries the same value
+    for (int it = 0; it < nchunks + 2; ++it) {
+        if (wave >= 2) {
+            const int h = tid - 128; // 0..127
+            if (it < nchunks) { // prepare chunk `it`
+                const int base = it * kChunk, valid = min(kChunk, n_complex - base);
+                float(*K)[kChunk] = sK[it & 1];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float x0 = (float)((int)((ws[j] >> sh) & 255u) - 127);
-                    const float x1 = (float)((int)((ws[j] >> (16 + sh)) & 255u) - 127);
-                    acc = acc * keep + k * x0;
-                    sA[lane][i + 2 * j] = acc;
-                    acc = acc * keep + k * x1;
-                    sA[lane][i + 2 * j + 1] = acc;
+                for (int q = 0; q < 4; ++q) {
+                    const int w = h + 128 * q; // word = 2 complex samples
+                    const unsigned u = (2 * w < valid) ? bytes4[(base >> 1) + w] : 0x7f7f7f7fu;
+                    K[0][2 * w] = k * (float)((int)(u & 255u) - 127);
+                    K[1][2 * w] = k * (float)((int)((u >> 8) & 255u) - 127);
+                    K[0][2 * w + 1] = k * (float)((int)((u >> 16) & 255u) - 127);
+                    K[1][2 * w + 1] = k * (float)((int)(u >> 24) - 127);
                 }
+            }
+            if (it >= 2) { // finish chunk `it - 2`: subtract, tile layout
+                const int c = it - 2, base = c * kChunk, valid = min(kChunk, n_complex - base);
+                const float(*A)[kChunk] = sA[c & 1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int unit = h + 128 * q, i2 = unit >> 6, ln = unit & 63;
+                    const int s0 = ln * kRun + 2 * i2;
+                    if (s0 < valid) {
+                        const unsigned u = bytes4[(base + s0) >> 1];
+                        float4 v = make_float4((float)((int)(u & 255u) - 127), (float)((int)((u >> 8) & 255u) - 127),
+                                               (float)((int)((u >> 16) & 255u) - 127), (float)((int)(u >> 24) - 127));
+                        v.x -= A[0][s0];
+                        v.y -= A[1][s0];
+                        v.z -= A[0][s0 + 1];
+                        v.w -= A[1][s0 + 1];
+                        tiled[tile_unit(c, i2, ln)] = v;
+                    }
+                }
+            }
+        } else if (it >= 1 && it <= nchunks) { // the recurrence of chunk `it - 1`, component `wave`
+            const int c = it - 1, valid = min(kChunk, n_complex - c * kChunk);
+            const float *K = sK[c & 1][wave];
+            float *A = sA[c & 1][wave];
+            // The products of the NEXT 16 samples are fetched while the chain works on the current 16 (an LDS latency per
+            // iteration would otherwise sit on the chain).  The optimiser sinks a plain load to its use in the next
+            // iteration, so the four ds_read_b128 are issued by hand and waited for after the chain.
+            const unsigned kaddr = (unsigned)(uintptr_t)K; // LDS byte address (the low half of the generic pointer)
+            v4f kq[4]; // (the same address in every lane: broadcast reads)
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+                         "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(kq[0]), "=&v"(kq[1]), "=&v"(kq[2]), "=&v"(kq[3])
+                         : "v"(kaddr)
+                         : "memory");
+            for (int j = 0; j < valid; j += 16) { // frames are multiples of 16 samples
+                v4f kn[4];
+                const unsigned an = kaddr + 4u * (unsigned)min(j + 16, kChunk - 16);
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+                             "ds_read_b128 %3, %4 offset:48"
+                             : "=&v"(kn[0]), "=&v"(kn[1]), "=&v"(kn[2]), "=&v"(kn[3])
+                             : "v"(an)
+                             : "memory");
+                float a[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc = acc * keep + kq[g].x;
+                    a[4 * g] = acc;
+                    acc = acc * keep + kq[g].y;
+                    a[4 * g + 1] = acc;
+                    acc = acc * keep + kq[g].z;
+                    a[4 * g + 2] = acc;
+                    acc = acc * keep + kq[g].w;
+                    a[4 * g + 3] = acc;
+                }
+                // the chain is done (its last value pinned) before the wait; the prefetched registers count as written here
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn[0]), "+v"(kn[1]), "+v"(kn[2]), "+v"(kn[3]), "+v"(acc)::"memory");
+                if (lane == 0) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4 *>(A + j + 4 * g) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    kq[g] = kn[g];
             }
         }
         __syncthreads();
-        // lane l owns samples 16 l .. 16 l + 15 of the chunk = 8 words of sB
-#pragma unroll
-        for (int i2 = 0; i2 < 8; ++i2) {
-            const int s0 = lane * kRun + 2 * i2;
-            const unsigned w = sB[s0 >> 1];
-            float4 v = make_float4((float)((int)(w & 255u) - 127), (float)((int)((w >> 8) & 255u) - 127),
-                                   (float)((int)((w >> 16) & 255u) - 127), (float)((int)(w >> 24) - 127));
-            v.x -= sA[0][s0];
-            v.y -= sA[1][s0];
-            v.z -= sA[0][s0 + 1];
-            v.w -= sA[1][s0 + 1];
-            if (s0 < valid)
-                tiled[tile_unit(c, i2, lane)] = v;
-        }
     }
-    if (lane < 2)
-        state[lane] = acc;
+    if (wave < 2 && lane == 0)
+        state[wave] = acc;
 }
 
 // The fast-arithmetic form of the same DC-bias removal (option "exact" = 0): the recurrence is

@@ -1406,7 +1406,7 @@ int enqueue_u8_device(sdrx_ctx *c, const void *dev_bytes, int n_complex, int cor
     }
     if (correct_dc && !c->opt_dc_blocked) {
         Bracket b(c, c->stream, KIND_INGEST, 0);
-        hipLaunchKernelGGL(k_ingest_u8_dc, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<const unsigned *>(dev_bytes),
+        hipLaunchKernelGGL(k_ingest_u8_dc, dim3(1), dim3(256), 0, c->stream, reinterpret_cast<const unsigned *>(dev_bytes),
                            reinterpret_cast<float4 *>(c->d_raw_tiled), n_complex, c->d_dc_state);
         mode = kRawTiled;
     } else if (correct_dc) {

@@ -96,7 +96,6 @@ def valu_derived(c, dur_us):
     if "SQ_WAVE_CYCLES" in c:
         wc = c["SQ_WAVE_CYCLES"]
         d["wave_cycles_split"] = {n: round(c[n] / wc, 3) for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if n in c}
-        d["resident_waves_per_simd"] = round(4 * wc / (N_SIMD * cycles), 2)
     if "SQ_ACTIVE_INST_LDS" in c:
         d["lds_inst_busy"] = round(4 * c["SQ_ACTIVE_INST_LDS"] / (N_SIMD * cycles), 3)
     return d
@@ -115,7 +114,7 @@ def calib(d, out):
             v = valu_derived(e["counters"], e["dur_us"])
             if v:
                 res["probes"][k] = {kk: v[kk] for kk in ("pass_dur_us", "clock_GHz", "valu_insts", "dual_issued_frac", "valu_busy_raw",
-                                                         "round2_formula_for_comparison", "resident_waves_per_simd") if kk in v}
+                                                         "round2_formula_for_comparison") if kk in v}
                 res["probes"][k]["cycles_per_inst"] = round(4.0 / max(1e-9, v["round2_formula_for_comparison"]), 3)
     try:
         res["git_sha"] = open(os.path.join(d, "build_sha.txt")).read().strip()
