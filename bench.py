@@ -139,7 +139,8 @@ def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix
     dom_bytes = d["alg_bytes"] / d["launches"]
     dom_avg_s = d["ms"] / d["launches"] * 1e-3
     achieved = dom_bytes / dom_avg_s / 1e9
-    r = {"bound": "hbm", "kernel": dom,  # (the roofline the contract prices against; what binds is `limiter`) "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # (`bound` is the roofline the contract prices against; what binds the launch is `limiter`, from the counters)
+    r = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
          "bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 5),
          "frame_kernel_ms": round(frame_kernel_ms, 5),
