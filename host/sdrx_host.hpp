@@ -335,118 +335,161 @@ struct Profile {
     std::vector<std::vector<vfo *>> subs; // per main (VFOsub[i], mainwindow.h:82)
 };
 
-// MainWindow::MainWindow's configuration part (mainwindow.cpp:27-233) on an INI stream.
-inline std::unique_ptr<Profile> load_profile(std::istream &in)
-{
-    const auto kv = parse_ini(in);
-    auto str = [&](const std::string &k) { auto it = kv.find(k); return it == kv.end() ? std::string() : it->second; };
-    auto toInt = [&](const std::string &k) { // QVariant(QString).toInt(): 0 when missing / not an integer
-        const std::string s = str(k);
+// ---- the INI front door ----------------------------------------------------------
+// The rules by which the reference turns its settings file into a VFO tree (mainwindow.cpp:27-233), restated as
+// three small pure steps -- settings access, frame geometry, sub-VFO placement -- and an instantiation step.
+
+// QSettings' view of the parsed file: missing or malformed numbers read as 0 (QVariant::toInt / toFloat).
+class Settings {
+public:
+    explicit Settings(std::map<std::string, std::string> kv) : kv_(std::move(kv)) {}
+    std::string text(const std::string &key) const
+    {
+        auto it = kv_.find(key);
+        return it == kv_.end() ? std::string() : it->second;
+    }
+    int integer(const std::string &key) const
+    {
+        const std::string s = text(key);
         if (s.empty())
             return 0;
         char *end = nullptr;
-        long long v = std::strtoll(s.c_str(), &end, 10);
-        if (*end != 0 || v < INT32_MIN || v > INT32_MAX)
-            return 0;
-        return (int)v;
-    };
-    auto toFloat = [&](const std::string &k) {
-        const std::string s = str(k);
+        const long long v = std::strtoll(s.c_str(), &end, 10);
+        return (*end != 0 || v < INT32_MIN || v > INT32_MAX) ? 0 : (int)v;
+    }
+    float real(const std::string &key) const
+    {
+        const std::string s = text(key);
         char *end = nullptr;
-        float v = std::strtof(s.c_str(), &end);
+        const float v = std::strtof(s.c_str(), &end);
         return (s.empty() || *end != 0) ? 0.0f : v;
-    };
-    auto P = std::unique_ptr<Profile>(new Profile());
-    const int Fs = toInt("sample_rate");
-    if (Fs == 0)
-        throw std::runtime_error("sample_rate ini file key not found or equal to zero"); // 31-37
-    if (Fs != 288000 && Fs != 1536000 && Fs != 1920000)                                  // mainwindow.h:29
-        throw std::runtime_error("sample_rate " + std::to_string(Fs) + " not supported");
-    P->fs = Fs;
-    P->center_frequency = toInt("center_frequency");
-    const int mix_offset = toInt("mix_offset");
-    int buflen; // "usually 4 buffers per Fs but in some cases 5 due to multiple of 512", 65-80
-    if (((2 * Fs) / 4) % 512 > 0) {
-        buflen = (2 * Fs) / 5;
-        P->bufsplit = 5;
-    } else {
-        buflen = (2 * Fs) / 4;
     }
-    P->frame = buflen / 2;
-    P->zmq_address = str("zmq_address");
-    P->correct_dc = str("correct_dc_bias") == "1";
-    const int center = P->center_frequency;
+    // `N\\key` array members of QSettings::beginReadArray(group): "<group>/<i>/<key>", i = 1 .. size
+    std::string item(const std::string &group, int i, const char *key) const { return group + "/" + std::to_string(i) + "/" + key; }
 
-    const int msize = toInt("main_vfos/size"); // 98-138
-    P->subs.resize((size_t)std::max(msize, 0));
-    for (int i = 1; i <= msize; ++i) {
-        const std::string p = "main_vfos/" + std::to_string(i) + "/";
-        const int vfo_freq = toInt(p + "frequency"), out_rate = toInt(p + "out_rate");
-        if (out_rate <= 0)
-            throw std::runtime_error(p + "out_rate missing");
-        vfo *v = new vfo();
-        P->all.emplace_back(v);
-        const int compscale = toInt(p + "compress_scale");
-        if (compscale > 0)
-            v->setScaleComp(compscale);
-        if (!str(p + "zmq_address").empty() && !str(p + "zmq_topic").empty()) {
-            v->setZmqAddress(str(p + "zmq_address"));
-            v->setZmqTopic(str(p + "zmq_topic"));
+private:
+    std::map<std::string, std::string> kv_;
+};
+
+// How many floats the ingest delivers per callback: a quarter of a second of I/Q, or a fifth where a quarter
+// is not a multiple of 512 floats (288 kS/s) -- mainwindow.cpp:65-80.
+struct FrameGeometry {
+    int floats_per_callback, callbacks_per_second;
+    int complex_per_frame() const { return floats_per_callback / 2; }
+};
+inline FrameGeometry frame_geometry(int sample_rate)
+{
+    const int quarter = 2 * sample_rate / 4;
+    if (quarter % 512 == 0)
+        return {quarter, 4};
+    return {2 * sample_rate / 5, 5};
+}
+
+// Where a sub VFO hangs and how it decimates, decided from the mains already configured
+// (mainwindow.cpp:179-216): the first IQ main whose output band covers the channel; below a 240 k / 288 k main
+// the last step to 48 k is the /5 or /6 FIR ("late decimation"), the half-bands do the rest.
+struct SubPlacement {
+    int main_index = 0, input_rate = 0, parent_mixer = 0, halfband_stages = 0, late_decimate = 0;
+};
+inline SubPlacement place_sub(const std::vector<vfo *> &mains, int receiver_rate, int center, int channel_freq, int out_rate)
+{
+    SubPlacement pl;
+    pl.input_rate = receiver_rate;
+    for (size_t a = 0; a < mains.size(); ++a) {
+        vfo &m = *mains[a];
+        const int main_centre = center - (int)m.getMixerFreq();
+        if (std::abs(main_centre - channel_freq) < m.getOutRate() && !m.getDemodUSB()) {
+            pl.main_index = (int)a;
+            pl.parent_mixer = (int)m.getMixerFreq();
+            pl.input_rate = m.getOutRate();
+            break;
         }
-        v->setFs(Fs);
-        v->setDecimationCount(Fs / out_rate == 1 ? 0 : (int)std::log2(Fs / out_rate));
-        v->setMixerFreq(center - vfo_freq);
-        v->setDemodUSB(false);
-        v->setCompressonStyle(1);
-        v->init(buflen / 2, false);
-        v->setVFOs(&P->subs[(size_t)i - 1]);
-        P->mains.push_back(v);
     }
-    const int size = toInt("vfos/size"); // 141-233
-    for (int i = 1; i <= size; ++i) {
-        const std::string p = "vfos/" + std::to_string(i) + "/";
-        const int vfo_freq = toInt(p + "frequency") + mix_offset;
-        const int data_rate = toInt(p + "data_rate");
-        int out_rate = toInt(p + "out_rate");
-        if (out_rate == 0 && data_rate > 0)
-            out_rate = data_rate == 600 ? 12000 : data_rate == 1200 ? 24000 : 48000;
+    const int fir_step = pl.input_rate / 48000; // 5 below a 240 k main, 6 below a 288 k one
+    if (fir_step == 5 || fir_step == 6) {
+        pl.late_decimate = fir_step;
+        pl.halfband_stages = (int)std::log2(pl.input_rate / (fir_step * out_rate));
+    } else {
+        pl.halfband_stages = (int)std::log2(receiver_rate / out_rate) - (int)std::log2(receiver_rate / pl.input_rate);
+    }
+    return pl;
+}
+
+inline std::unique_ptr<Profile> load_profile(std::istream &in)
+{
+    const Settings ini(parse_ini(in));
+    auto prof = std::unique_ptr<Profile>(new Profile());
+    Profile &P = *prof;
+    P.fs = ini.integer("sample_rate");
+    if (P.fs == 0)
+        throw std::runtime_error("sample_rate ini file key not found or equal to zero"); // mainwindow.cpp:31-37
+    if (P.fs != 288000 && P.fs != 1536000 && P.fs != 1920000)                            // mainwindow.h:29
+        throw std::runtime_error("sample_rate " + std::to_string(P.fs) + " not supported");
+    const FrameGeometry geo = frame_geometry(P.fs);
+    P.frame = geo.complex_per_frame();
+    P.bufsplit = geo.callbacks_per_second;
+    P.center_frequency = ini.integer("center_frequency");
+    P.zmq_address = ini.text("zmq_address");
+    P.correct_dc = ini.text("correct_dc_bias") == "1";
+    const int channel_offset = ini.integer("mix_offset");
+
+    // main VFOs: IQ only, compress() style 1, fed by the raw stream (mainwindow.cpp:98-138)
+    const int n_mains = std::max(0, ini.integer("main_vfos/size"));
+    P.subs.resize((size_t)n_mains);
+    for (int i = 1; i <= n_mains; ++i) {
+        auto key = [&](const char *k) { return ini.item("main_vfos", i, k); };
+        const int out_rate = ini.integer(key("out_rate"));
         if (out_rate <= 0)
-            throw std::runtime_error(p + ": neither out_rate nor data_rate given");
-        if (P->mains.empty())
+            throw std::runtime_error(key("out_rate") + " missing");
+        P.all.emplace_back(new vfo());
+        vfo &m = *P.all.back();
+        if (const int scale = ini.integer(key("compress_scale")))
+            if (scale > 0)
+                m.setScaleComp(scale);
+        if (!ini.text(key("zmq_address")).empty() && !ini.text(key("zmq_topic")).empty()) {
+            m.setZmqAddress(ini.text(key("zmq_address")));
+            m.setZmqTopic(ini.text(key("zmq_topic")));
+        }
+        m.setFs(P.fs);
+        m.setDecimationCount(P.fs / out_rate == 1 ? 0 : (int)std::log2(P.fs / out_rate));
+        m.setMixerFreq(P.center_frequency - ini.integer(key("frequency")));
+        m.setDemodUSB(false);
+        m.setCompressonStyle(1);
+        m.init(P.frame, false);
+        m.setVFOs(&P.subs[(size_t)i - 1]);
+        P.mains.push_back(&m);
+    }
+
+    // sub VFOs: USB audio leaves under the main that covers them (mainwindow.cpp:141-233)
+    const int n_subs = ini.integer("vfos/size");
+    for (int i = 1; i <= n_subs; ++i) {
+        auto key = [&](const char *k) { return ini.item("vfos", i, k); };
+        int out_rate = ini.integer(key("out_rate"));
+        if (out_rate == 0) { // the older profiles give the data rate of the channel instead
+            const int data_rate = ini.integer(key("data_rate"));
+            if (data_rate > 0)
+                out_rate = data_rate == 600 ? 12000 : data_rate == 1200 ? 24000 : 48000;
+        }
+        if (out_rate <= 0)
+            throw std::runtime_error(ini.item("vfos", i, "") + ": neither out_rate nor data_rate given");
+        if (P.mains.empty())
             throw std::runtime_error("profile has sub VFOs but no main VFO");
-        int main_vfo_freq = 0, main_vfo_out_rate = Fs, main_idx = 0;
-        for (size_t a = 0; a < P->mains.size(); ++a) { // first main whose band covers the VFO, 179-191
-            const int diff = std::abs((center - (int)P->mains[a]->getMixerFreq()) - vfo_freq);
-            if (diff < P->mains[a]->getOutRate() && !P->mains[a]->getDemodUSB()) {
-                main_idx = (int)a;
-                main_vfo_freq = (int)P->mains[a]->getMixerFreq();
-                main_vfo_out_rate = P->mains[a]->getOutRate();
-                break;
-            }
-        }
-        vfo *v = new vfo();
-        P->all.emplace_back(v);
-        v->setZmqTopic(str(p + "topic"));
-        v->setZmqAddress(P->zmq_address);
-        int lateDecimate = 0; // 196-216
-        if (main_vfo_out_rate / 48000 == 5) {
-            v->setDecimationCount((int)std::log2(main_vfo_out_rate / (5 * out_rate)));
-            lateDecimate = 5;
-        } else if (main_vfo_out_rate / 48000 == 6) {
-            v->setDecimationCount((int)std::log2(main_vfo_out_rate / (6 * out_rate)));
-            lateDecimate = 6;
-        } else {
-            v->setDecimationCount((int)std::log2(Fs / out_rate) - (int)std::log2(Fs / main_vfo_out_rate));
-        }
-        v->setFilterBandwidth(toInt(p + "filter_bandwidth"));
-        v->setGain(toFloat(p + "gain") / 100);
-        v->setMixerFreq((center - main_vfo_freq) - vfo_freq);
-        v->setFs(main_vfo_out_rate);
-        v->setCompressonStyle(1);
-        v->init(main_vfo_out_rate / P->bufsplit, true, lateDecimate);
-        P->subs[(size_t)main_idx].push_back(v);
+        const int channel = ini.integer(key("frequency")) + channel_offset;
+        const SubPlacement pl = place_sub(P.mains, P.fs, P.center_frequency, channel, out_rate);
+        P.all.emplace_back(new vfo());
+        vfo &v = *P.all.back();
+        v.setZmqTopic(ini.text(key("topic")));
+        v.setZmqAddress(P.zmq_address);
+        v.setDecimationCount(pl.halfband_stages);
+        v.setFilterBandwidth(ini.integer(key("filter_bandwidth")));
+        v.setGain(ini.real(key("gain")) / 100);
+        v.setMixerFreq((P.center_frequency - pl.parent_mixer) - channel);
+        v.setFs(pl.input_rate);
+        v.setCompressonStyle(1);
+        v.init(pl.input_rate / P.bufsplit, true, pl.late_decimate);
+        P.subs[(size_t)pl.main_index].push_back(&v);
     }
-    return P;
+    return prof;
 }
 
 inline std::unique_ptr<Profile> load_profile_file(const std::string &path)
