@@ -84,8 +84,8 @@ struct Upload {
 };
 std::unordered_map<int, Upload> &uploads()
 {
-    static std::unordered_map<int, Upload> u;
-    return u;
+    static auto *u = new std::unordered_map<int, Upload>();
+    return *u;
 }
 int g_fft_taps = 0; // VFOs anywhere in the process with an fftData tap selected (vfo::fftVFOSlot)
 void take_probe(const float *iq, size_t n_floats, float *probe)
@@ -114,10 +114,12 @@ struct NodeState {
     std::shared_ptr<Tree> tree; // the tree this object was committed to (shared by all its nodes)
 };
 
+// (both registries are deliberately never destroyed: vfo objects -- and through them trees -- may outlive any
+// static of this file at process exit)
 std::unordered_map<const vfo *, NodeState> &side()
 {
-    static std::unordered_map<const vfo *, NodeState> s;
-    return s;
+    static auto *s = new std::unordered_map<const vfo *, NodeState>();
+    return *s;
 }
 
 std::vector<int> devices_from_env()
