@@ -611,6 +611,54 @@ __device__ __forceinline__ void hb_stage_lds(v2f *__restrict__ A, v2f *__restric
         A[lane] = t;
 }
 
+// The same LDS stages 2 .. D-1 for the common case -- a FULL chunk (1024 inputs) of a leaf VFO (natural-order output)
+// that does not hold the frame's last sample -- with the depth as a compile-time constant: every count, LDS offset
+// and trip count folds, the per-stage loop, the tiled / natural and last / not-last selects and the save branch
+// disappear (the generic routine spends about as many VALU instructions on them as on the 11-operation dot product).
+// Same arithmetic, same order, same LDS contents afterwards.  -DSDRX_FIXED_STAGES=0 switches it off (A/B).
+#ifndef SDRX_FIXED_STAGES
+#define SDRX_FIXED_STAGES 1
+#endif
+constexpr int kFixedDepth = 5; // 1.536 MS/s / 384 kS/s -> 48 / 12 kS/s: the depth of the reference's sub VFOs below a 384 k main
+template <bool EXACT, int S, int D>
+__device__ __forceinline__ void hb_stage_fixed(v2f *__restrict__ lds, float2 *__restrict__ gout, int gbase, int jmin, int lane)
+{
+    constexpr int cnt = kChunk >> S, nout = cnt >> 1;
+    v2f *A = lds + stage_offset(S);
+    v2f *B = lds + stage_offset(S + 1); // (not touched by the last stage)
+    wave_sync(); // stage input (written by the previous phase) is visible
+    if constexpr (nout >= 64) {
+#pragma unroll
+        for (int it = 0; it < nout / 64; ++it) {
+            const int j = lane + 64 * it;
+            const v2f *w = A + kCarry + 2 * j - 10;
+            const v2f y = hb_dot2<EXACT>(w[0], w[2], w[4], w[5], w[6], w[8], w[10]);
+            if constexpr (S + 1 < D)
+                B[kCarry + j] = y;
+            else if (j >= jmin)
+                gstv2_leaf(gout + (size_t)(gbase + j), y);
+        }
+    } else {
+        if (lane < nout) {
+            const v2f *w = A + kCarry + 2 * lane - 10;
+            const v2f y = hb_dot2<EXACT>(w[0], w[2], w[4], w[5], w[6], w[8], w[10]);
+            if constexpr (S + 1 < D)
+                B[kCarry + lane] = y;
+            else if (lane >= jmin)
+                gstv2_leaf(gout + (size_t)(gbase + lane), y);
+        }
+    }
+    wave_sync(); // all window reads done before the carry is overwritten
+    v2f t;
+    if (lane < kCarry)
+        t = A[cnt + lane]; // the last 16 of [carry | data]
+    wave_sync();
+    if (lane < kCarry)
+        A[lane] = t;
+    if constexpr (S + 1 < D)
+        hb_stage_fixed<EXACT, S + 1, D>(lds, gout, gbase, jmin, lane);
+}
+
 // NOUT outputs of a register-resident stage.  ext[k] holds input sample k-10 of this lane's run
 // (k = 0..9: the halo, only the needed ones set).
 template <bool EXACT, int NOUT>
@@ -1044,6 +1092,14 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         if (emit && lane < 32) // ablation: skip the LDS stages, write something that depends on z
             gstv2(out + (base >> D.d) + lane, z[0] + z[1] + z[2] + z[3]);
         continue;
+#endif
+#if SDRX_FIXED_STAGES && !SDRX_GLDS
+        if (valid == kChunk && !save && !D.out_tiled && D.d == kFixedDepth) { // (uniform) a full chunk of a leaf, not the frame's last
+            // outputs below jmin belong to the warm-up of a segment that starts inside the frame
+            const int jmin = max(0, (first_out - base) >> D.d), gbase = base >> D.d;
+            hb_stage_fixed<EXACT, 2, kFixedDepth>(lds, out, gbase, jmin, lane);
+            continue;
+        }
 #endif
         for (int s = kRegStages; s < D.d; ++s) {
             if (s + 1 == D.d)
