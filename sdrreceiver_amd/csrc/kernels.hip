@@ -731,7 +731,12 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
     const int first_out = D.n_in == 12345 ? W.s_first_out : 0x7fffffff; // ablation: nothing is ever emitted
 #endif
     const int lane16 = (W.s_begin >> 4) + lane; // this lane's run in the item's first chunk, in units of 16 samples
-    const float4 *src_item = in + tile_unit(lane16 >> 6, 0, lane16 & 63);
+    // the lane's first 16-byte unit of the item as a 32-bit index (a frame has < 2^20 units): the loads below then take the
+    // uniform stream pointer from SGPRs and one 32-bit VGPR offset instead of keeping a 64-bit pointer alive per lane
+    const unsigned unit_item = (unsigned)(lane16 >> 6) * 512u + (unsigned)(lane16 & 63);
+#if SDRX_GLDS
+    const float4 *src_item = in + unit_item;
+#endif
 #if SDRX_GLDS
     // items fed from a tile-layout stream (every sub VFO; a wide level 0) take their tiles through the LDS-DMA slot
     const bool tile_in = !(level0 && raw_mode != kRawTiled);
@@ -803,7 +808,11 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
             // advances by exactly one tile per chunk): src_item is computed once, a chunk adds 512
             // units.  A shifted walk straddles two tiles; its idle lanes in the frame's last chunk may
             // read the (zero) tile behind the last one, which every tile-layout buffer has.
+#if SDRX_GLDS
             const float4 *src = src_item + (size_t)((base - W.s_begin) >> 10) * 512;
+#else
+            const float4 *src = in + (unit_item + (unsigned)((base - W.s_begin) >> 10) * 512u);
+#endif
 #if SDRX_GLDS == 0
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
