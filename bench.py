@@ -173,6 +173,7 @@ def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix
             valu["inst_mix_per_chunk"] = pm["inst_mix"]
         r["valu"] = valu
         busy = valu.get("valu_busy", valu.get("valu_busy_raw", 0.0))
+        r["valu_busy"] = busy  # the fraction of what really binds the launch (calibrated; details in `valu`)
         hb = r.get("hbm_true_frac", 0.0)
         r["limiter"] = "valu" if busy > hb else "hbm"
         r["limited_by"] = (f"VALU issue: {busy:.0%} of the launch's cycles carry a VALU instruction (calibrated) -- not HBM: real traffic "
