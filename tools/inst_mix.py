@@ -8,11 +8,15 @@
     stage 0      8 x (3 pair sums + 4 products + 3 sums + (0 + s))  [4 pk_mul + 7 pk_add]                 =  88
     stage 1      4 x the same                                                                             =  44
     halos       16 complex values shifted one lane (wave_shr:1), 2 v_mov_b32_dpp each                     =  32
-    LDS stages  one rolled instance of the same 11-instruction dot product (run 2 + 1 + 1 times per lane)
+    LDS stages  the same 11-instruction dot product, run 2 + 1 + 1 times per lane: ONE rolled instance in the generic routine
+                (hb_stage_lds: any depth, frame end, tiled output) + the FOUR unrolled instances of hb_stage_fixed (full chunk
+                of a d = 5 leaf: the path 374 of 375 chunks take)
 
 The register-resident part is straight-line code, so the STATIC counts of the kernel must be exactly
-  v_pk_mul_f32 = 64 + 32 + 32 + 16 + 4 = 148,  v_pk_add_f32 = 56 + 28 + 7 = 91,  v_pk_fma_f32 = 16 + 16 = 32,  *_dpp = 32
-which this script checks (exact arithmetic, level >= 1 instantiation)."""
+  v_pk_mul_f32 = 64 + 32 + 32 + 16 + 4 (generic stage) + 16 (fixed stages) = 164,
+  v_pk_add_f32 = 56 + 28 + 7 + 28 = 119,  v_pk_fma_f32 = 16 + 16 = 32,  *_dpp = 32
+which this script checks (exact arithmetic, level >= 1 instantiation).  Per chunk of a d = 5 leaf a wave EXECUTES
+148 / 91 / 32 / 32 of them, either way."""
 import os
 import re
 import sys
@@ -20,7 +24,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "sdrreceiver_amd", "csrc", "kernels.s")
 lines = open(path).read().splitlines()
-want = {"v_pk_mul_f32": 148, "v_pk_add_f32": 91, "v_pk_fma_f32": 32, "dpp": 32}
+want = {"v_pk_mul_f32": 164, "v_pk_add_f32": 119, "v_pk_fma_f32": 32, "dpp": 32}
 ok = True
 for sym, label in (("_ZN4sdrx14k_mix_decimateILb1ELi1EEE", "k_mix_decimate<exact, level>=1>"), ("_ZN4sdrx12k_mix_levelsILb1EEE", "k_mix_levels<exact>")):
     start = next((i for i, l in enumerate(lines) if l.startswith(sym) and l.rstrip().endswith(":") or (l.startswith(sym) and ": " in l)), None)
