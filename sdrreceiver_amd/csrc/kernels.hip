@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256) void k_ingest_u8(const unsigned *__restrict__ 
 //   wave 0 / 1 run the I / the Q recurrence of chunk c: per 4 samples one broadcast ds_read_b128 of the prepared
 //              products, 4 x (v_mul, v_add) on a wave-uniform accumulator, one ds_write_b128 of the 4 estimates;
 //   waves 2-3  finish chunk c-1: curr - avept, stored in tile layout.
-// One __syncthreads() per chunk.  Measured: 9.8 ms per 384 000-sample frame for the one-wave version of rounds 1-2
-// (whose "1.7 ms" was an estimate), see profiles/README.md for this one.
+// One __syncthreads() per chunk.  Measured: 4.5 ms per 384 000-sample frame (the one-wave version of rounds 1-2 took
+// 9.3 ms; the "1.7 ms" of the round-2 documents was an estimate).
 __global__ __launch_bounds__(256) void k_ingest_u8_dc(const unsigned *__restrict__ bytes4, float4 *__restrict__ tiled, int n_complex,
                                                       float *__restrict__ state)
 {

@@ -561,7 +561,7 @@ def test_u8_dc_bias_blocked_scan_option(Receiver):
     The reference's fp32 recurrence itself wanders around the true response (its rounding errors
     are correlated from step to step: up to 8e-3 here at a 3-LSB offset), which is why the option
     is off by default; the deviation is measured and bounded here.  The scan must also be >= 15x
-    faster than the exact one-wave recurrence (~1.7 ms per frame)."""
+    faster than the exact recurrence (4.5 ms per frame)."""
     import scipy.signal as sg
     topo = tp.config2()
     rx = Receiver.from_topology(topo, exact=True, keep_prequant=True, dc_blocked_scan=True)
