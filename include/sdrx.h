@@ -98,7 +98,7 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
  *            sdrx_fetch / sdrx_get_* (which run what is outstanding).  0 = every call runs its frame through
  *            all levels at once.  Results are bit-identical either way.
  *   "dc_blocked_scan" 0|1 (default 0): how sdrx_process_u8 removes the DC bias.  0 = the
- *                 reference's sequentially rounded fp32 recurrence, bit for bit (one wave,
+ *                 reference's sequentially rounded fp32 recurrence, bit for bit (one workgroup,
  *                 ~4.5 ms per 384 000-sample frame).  1 = the same linear filter as a blocked
  *                 parallel scan (~15 us): the true IIR response.  The reference's recurrence
  *                 wanders around that by up to ~3e-3 of the DC offset (its rounding errors are
