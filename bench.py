@@ -133,6 +133,14 @@ def pmc_for(workload, exact):
     return None
 
 
+def build_id():
+    try:
+        from sdrreceiver_amd import _lib
+        return _lib.lib().sdrx_build_id().decode()
+    except Exception:
+        return "unknown"
+
+
 def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix_chunks):
     """SURVEY.md 8d's contract figure (algorithmic bytes / launch duration vs 8 TB/s) plus what the
     counters say actually bounds the launch: real HBM traffic, L2 hit rate, VALU issue."""
@@ -152,6 +160,10 @@ def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix
     cn = k.get("counters", {})
     r["traffic_source"] = pm.get("source")
     r["pmc_git_sha"] = pm.get("git_sha")
+    # the counter passes name the library they measured (sdrx_build_id, a hash of the kernel / host sources): a mismatch
+    # means the committed counters are from an older build than the one timed here
+    r["pmc_build_id"] = pm.get("build_id")
+    r["pmc_matches_build"] = (pm.get("build_id") == build_id()) if pm.get("build_id") else None
     if "hbm_bytes_per_launch" in k:
         r["traffic"] = int(k["hbm_bytes_per_launch"])
         r["hbm_true_GBps"] = round(r["traffic"] / dom_avg_s / 1e9, 1)
@@ -523,6 +535,7 @@ def main():
         value = args.steps * vfo_samples / dt / 1e6
         out = {
             "metric": "IQ MSamples/s ingested, summed over VFO chains (1.536 MS/s -> 48/12 kHz USB chain)",
+            "build_id": build_id(),
             "value": round(value, 2), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if workload == "config5" else "weak", "vs_baseline": None,

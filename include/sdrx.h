@@ -71,6 +71,9 @@ typedef void (*sdrx_publish_fn)(void *user, const char topic[5], uint32_t sample
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 int sdrx_abi_version(void);
+/* A short hash of the sources this library was compiled from (csrc/Makefile): what profiles and bench lines name as the
+ * build they measured. */
+const char *sdrx_build_id(void);
 int sdrx_create(sdrx_ctx **ctx, int device_ordinal);
 int sdrx_destroy(sdrx_ctx *ctx);
 const char *sdrx_last_error(const sdrx_ctx *ctx); /* ctx may be NULL: error of a failed create */

@@ -46,6 +46,7 @@ PUBLISH_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_char), C.c_uint32, C.c_
 _vp, _i = C.c_void_p, C.c_int
 SYMBOLS = {
     "sdrx_abi_version": (_i, []),
+    "sdrx_build_id": (C.c_char_p, []),
     "sdrx_create": (_i, [C.POINTER(_vp), _i]),
     "sdrx_destroy": (_i, [_vp]),
     "sdrx_last_error": (C.c_char_p, [_vp]),

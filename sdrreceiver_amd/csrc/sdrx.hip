@@ -558,6 +558,11 @@ extern "C" {
 
 int sdrx_abi_version(void) { return SDRX_ABI_VERSION; }
 
+#ifndef SDRX_SOURCE_HASH
+#define SDRX_SOURCE_HASH "unknown"
+#endif
+const char *sdrx_build_id(void) { return SDRX_SOURCE_HASH; }
+
 const char *sdrx_last_error(const sdrx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 const char *sdrx_kernel_name(int kind) { return kind >= 0 && kind < SDRX_NKERNELS ? kKindNames[kind] : ""; }

@@ -136,6 +136,12 @@ def main():
         sha = open(os.path.join(d, "build_sha.txt")).read().strip()
     except OSError:
         pass
+    build_id = None
+    for name in ("bench.json", "bench_unprofiled.json"):  # the bench line of the same profile run names the library
+        try:
+            build_id = json.loads(open(os.path.join(d, name)).read().strip().splitlines()[-1]).get("build_id") or build_id
+        except (OSError, ValueError, IndexError):
+            pass
     sat = {}
     try:
         cal = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "valu_calibration.json")))
@@ -149,7 +155,7 @@ def main():
             k = key_of(r["Name"])
             if k:
                 avg_us[k] = float(r["AverageNs"]) / 1e3
-    res = {"source": os.path.relpath(d), "git_sha": sha, "workload": workload, "exact": exact, "kernels": {},
+    res = {"source": os.path.relpath(d), "git_sha": sha, "build_id": build_id, "workload": workload, "exact": exact, "kernels": {},
            "inst_mix": {"k_mix_decimate, d=5 sub VFO, per 1024-sample chunk (source count, packed = 1)": INST_MIX_D5,
                         "sum": sum(INST_MIX_D5.values()),
                         "isa_check": "tools/inst_mix.py: the static v_pk_mul/add/fma_f32 and DPP counts of kernels.s == the source count (148/91/32/32 executed per chunk; +16/+28 static for the unrolled fixed-depth LDS stages)"},
