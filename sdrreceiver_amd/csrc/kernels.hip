@@ -957,11 +957,13 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
                 if (emit) {
                     // pad0(128 i + 2 lane) = 144 i + pad0(2 lane): one base address, constant offsets
                     const v2f *src = lds + pad0(2 * lane);
-                    float2 *dst = out + base + 2 * lane;
+                    // (a 32-bit sample index per lane on top of the uniform stream pointer: a 64-bit per-lane pointer kept
+                    // alive across the chunk loop was what the register allocator spilled)
+                    const unsigned at = (unsigned)base + 2u * (unsigned)lane;
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
                         if (128 * i + 2 * lane < valid && base + 128 * i + 2 * lane >= first_out)
-                            gstv4(reinterpret_cast<float4 *>(dst + 128 * i), *reinterpret_cast<const v4f *>(src + 144 * i));
+                            gstv4_leaf(reinterpret_cast<float4 *>(out + (at + 128u * i)), *reinterpret_cast<const v4f *>(src + 144 * i));
                 }
             }
             continue;
