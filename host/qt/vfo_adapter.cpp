@@ -62,6 +62,8 @@ struct Tree {
     int device = 0;
     bool pipelined = false;    // SDRX_PIPELINE=1
     int in_flight = 0;         // frames submitted and not yet delivered
+    const vfo *tap = nullptr;  // the node sdrx_set_tap was last told about (fftVFOSlot) ...
+    sdrx_ctx *tap_ctx = nullptr; // ... and the context that holds it
     ~Tree();
     const char *error() const { return grp ? sdrx_group_last_error(grp) : sdrx_last_error(ctx); }
     // deliver the oldest submitted frame: payloads -> transmit buffers -> ZmqPublisher, in the reference's order
@@ -348,6 +350,36 @@ void vfo::process(const std::vector<cpx_typef> &samples)
     const int n = (int)samples.size();
     // (any tap anywhere makes EVERY tree deliver at once: the trees of one receiver stay in step with each other)
     const bool want_fft = g_fft_taps > 0;
+    // fftVFOSlot selected a node of this tree (vfo.cpp:492-509): the library must know BEFORE the frame runs -- a leaf whose
+    // late decimation is fused into the mix wave keeps decimate[0] only while it is the tap (sdrx_set_tap)
+    {
+        const vfo *want = nullptr;
+        for (vfo *v : T.nodes)
+            if (v->emitFFT) {
+                want = v;
+                break;
+            }
+        if (want != T.tap) {
+            while (T.in_flight > 0)
+                T.deliver_one();
+            if (T.tap_ctx && sdrx_set_tap(T.tap_ctx, -1) != SDRX_OK)
+                qFatal("sdrx adapter: sdrx_set_tap: %s", sdrx_last_error(T.tap_ctx));
+            T.tap_ctx = nullptr;
+            if (want) {
+                int id = side()[want].id;
+                sdrx_ctx *c = T.ctx;
+                if (T.grp) {
+                    int member = -1;
+                    if (sdrx_group_locate(T.grp, id, &member, &id) != SDRX_OK || sdrx_group_member(T.grp, member, &c, nullptr) != SDRX_OK || !c)
+                        qFatal("sdrx adapter: sdrx_group_locate: %s", T.error());
+                }
+                if (sdrx_set_tap(c, id) != SDRX_OK)
+                    qFatal("sdrx adapter: sdrx_set_tap: %s", sdrx_last_error(c));
+                T.tap_ctx = c;
+            }
+            T.tap = want;
+        }
+    }
     // who uploads: this tree, unless another tree on the device already holds exactly this frame
     sdrx_ctx *shared_from = nullptr;
     if (T.ctx && n > 0 && !(std::getenv("SDRX_SHARE_UPLOAD") && std::atoi(std::getenv("SDRX_SHARE_UPLOAD")) == 0)) {

@@ -148,6 +148,7 @@ public:
             dc_correct(samples_);
             in = samples_.data();
         }
+        select_tap();
         if (grp_)
             check(sdrx_group_process(grp_, in, len / 2), "sdrx_group_process");
         else
@@ -161,6 +162,7 @@ public:
     {
         if (!started())
             start();
+        select_tap();
         if (!grp_) {
             check(sdrx_process_u8(ctx_, bytes, n_complex, correctDC ? 1 : 0), "sdrx_process_u8");
         } else {
@@ -202,6 +204,28 @@ private:
         check(sdrx_group_locate(grp_, id, &member, local), "sdrx_group_locate");
         check(sdrx_group_member(grp_, member, &c, nullptr), "sdrx_group_member");
         return c;
+    }
+    // fftVFOSlot selected a VFO (vfo.cpp:492-509): tell the library before the frame runs -- a leaf whose late decimation
+    // is fused into the mix wave keeps decimate[0] only while it is the tap (sdrx_set_tap)
+    void select_tap()
+    {
+        vfo *want = nullptr;
+        for (vfo *v : all_)
+            if (v->emitFFT && v->fftData) {
+                want = v;
+                break;
+            }
+        if (want == tap_vfo_)
+            return;
+        if (tap_ctx_)
+            check_ctx(tap_ctx_, sdrx_set_tap(tap_ctx_, -1), "sdrx_set_tap");
+        tap_ctx_ = nullptr;
+        if (want) {
+            int lid = -1;
+            tap_ctx_ = locate(want->id, &lid);
+            check_ctx(tap_ctx_, sdrx_set_tap(tap_ctx_, lid), "sdrx_set_tap");
+        }
+        tap_vfo_ = want;
     }
     // vfo::process ends with `if (emitFFT) emit fftData(decimate[decimateCount])` (vfo.cpp:290-293);
     // demodData with `if (count == 4 && emitFFT) { emit fftData(samples); count = 0; } count++`.
@@ -282,6 +306,8 @@ private:
     int count = 0;
     std::vector<vfo *> all_;
     std::vector<std::complex<float>> tap_;
+    vfo *tap_vfo_ = nullptr;     // the VFO sdrx_set_tap was last told about ...
+    sdrx_ctx *tap_ctx_ = nullptr; // ... and the context that holds it
     float avept_[2] = {0.f, 0.f};
     std::vector<float> samples_;
     publish_fn publish_;

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SDRX_ABI_VERSION 3
+#define SDRX_ABI_VERSION 4
 
 enum {
     SDRX_OK = 0,
@@ -100,6 +100,14 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
  *            sdrx_process_device is only COMPLETE after the next such call or after sdrx_sync /
  *            sdrx_fetch / sdrx_get_* (which run what is outstanding).  0 = every call runs its frame through
  *            all levels at once.  Results are bit-identical either way.
+ *   "fuse_late" 1 (default) | 0: a USB leaf with decimate_count 0 and late_decimate 5 | 6 below a parent
+ *            (vfo::usb_decimdemod, vfo.cpp:334-387: the reference mixes, low-passes and keeps every 5th / 6th
+ *            sample in one pass) runs its decimating low-pass inside the mix wave and writes only the decimated
+ *            stream to HBM; decimate[0] of such a leaf is kept only while it is the tap (sdrx_set_tap) or with
+ *            "keep_streams".  0 = the two-kernel form (the mixed stream goes to HBM and comes back): A/B switch.
+ *            Results are bit-identical either way.
+ *   "keep_streams" 0 (default) | 1: every such leaf also keeps decimate[0] of every frame (parity tests that
+ *            compare every stream of the tree).
  *   "dc_blocked_scan" 0|1 (default 0): how sdrx_process_u8 removes the DC bias.  0 = the
  *                 reference's sequentially rounded fp32 recurrence, bit for bit (one workgroup,
  *                 ~4.5 ms per 384 000-sample frame).  1 = the same linear filter as a blocked
@@ -186,6 +194,12 @@ int sdrx_get_output(sdrx_ctx *ctx, int id, const void **buf, uint32_t *len_bytes
 /* decimate[decimateCount] of node `id` (public member vfo.h:39 -- what the fftData signal
  * carries, vfo.cpp:290-293): copies up to max_complex cf32 to `out`, returns the count in *n. */
 int sdrx_get_stream(sdrx_ctx *ctx, int id, float *out_iq, int max_complex, int *n);
+/* fftVFOSlot(topic) (vfo.cpp:492-509, sdrj.cpp:84-101): the GUI names ONE VFO whose decimate[decimateCount] it wants
+ * from the next frame on.  Every node keeps that stream in HBM anyway, with one exception: a leaf whose late decimation
+ * is fused into the mix wave (option "fuse_late") writes only its decimated stream -- sdrx_get_stream on it returns
+ * SDRX_ESTATE unless it was selected here before the frame was processed (or "keep_streams" is set).  id = -1: none.
+ * Not while submitted frames are in flight. */
+int sdrx_set_tap(sdrx_ctx *ctx, int id);
 /* The raw frame exactly as the parent-less VFOs consumed it -- `samples` of sdrj::demodData
  * (sdrj.cpp:266-305) after the byte LUT and the DC-bias removal, what sdrj's own fftData signal
  * carries (sdrj.cpp:296-303) -- natural order, cf32.  Available after sdrx_process and

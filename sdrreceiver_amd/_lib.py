@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("SDRX_LIB") or os.path.join(_HERE, "libsdrx.so")  # SD
 CSRC = os.path.join(_HERE, "csrc")
 
 NKERNELS = 8
+SDRX_EINVAL, SDRX_ESTATE, SDRX_EFILTER, SDRX_EHIP, SDRX_EUNSUPPORTED = -1, -2, -3, -4, -5  # include/sdrx.h
 
 
 class VfoDescC(C.Structure):
@@ -68,6 +69,7 @@ SYMBOLS = {
     "sdrx_set_stream": (_i, [_vp, _vp]),
     "sdrx_get_output": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sdrx_get_stream": (_i, [_vp, _i, _vp, _i, C.POINTER(_i)]),
+    "sdrx_set_tap": (_i, [_vp, _i]),
     "sdrx_get_raw": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     "sdrx_get_prequant": (_i, [_vp, _i, _vp, _i, C.POINTER(_i)]),
     "sdrx_get_taps": (_i, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),

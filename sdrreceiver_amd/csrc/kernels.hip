@@ -83,6 +83,32 @@ __device__ __forceinline__ v2f cmul(v2f a, v2f b)
     const v2f pm = {-1.0f, 1.0f};
     return __builtin_elementwise_fma(t2, pm, t1);
 }
+// (h, h) * w and fma((h, h), w, c) with h = the low (HI = 0) or high (HI = 1) half of a PAIR of taps: op_sel / op_sel_hi pick
+// that half for both lanes of the packed instruction.  (Written as `v2f{h, h} * w` the compiler materialises the pair
+// (h, h) with two v_mov per tap, and the registers to hold them.)  Each lane is an ordinary IEEE fp32 operation.
+// `after`: a value the product is to be computed AFTER (an operand the instruction does not read).  The products of a FIR
+// do not depend on its accumulators, so a scheduler is free to compute all of them first -- and spill them; tied to the
+// accumulator they are added to, at most one product per chain is in flight.
+template <int HI>
+__device__ __forceinline__ v2f pk_mul_bcast(v2f hpair, v2f w, v2f after)
+{
+    v2f r;
+    if (HI)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(hpair), "v"(w), "v"(after));
+    else
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(hpair), "v"(w), "v"(after));
+    return r;
+}
+template <int HI>
+__device__ __forceinline__ v2f pk_fma_bcast(v2f hpair, v2f w, v2f c)
+{
+    v2f r;
+    if (HI)
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(hpair), "v"(w), "v"(c));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(hpair), "v"(w), "v"(c));
+    return r;
+}
 __device__ __forceinline__ v2f gldv2(const float2 *p) { return *(const SDRX_AS1 v2f *)p; }
 __device__ __forceinline__ v4f gldv4(const float4 *p) { return *(const SDRX_AS1 v4f *)p; }
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -1122,6 +1148,199 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
 #undef GLDS_PRE_STORE
 }
 
+// ------------------------------------------------------------------------------------ late_item
+// vfo::usb_decimdemod's first half (vfo.cpp:334-356) for a d = 0 leaf, INSIDE the mix wave: NCO + mixer as in mix_item,
+// then the decimating low-pass on the mixed samples while they are still on the CU,
+//     z'[k] = sum_{t < Nd} hd[t] * x[L k - Nd + t]         (FIR::FIRUpdateAndProcess: the (Nd+1)-slot ring leaves the newest
+//                                                            sample x[L k] out, dsp.cpp:59-71; FIRUpdate for the samples
+//                                                            in between, dsp.cpp:150-154; the phase counter restarts with
+//                                                            every frame, vfo.cpp:338-339, and frames are multiples of L)
+// so that only z' (1 / L of the bytes) goes to HBM: the two-kernel form wrote the mixed 240 kS/s stream for
+// k_late_decimate4 to read back, 246 MB per frame on BASELINE config 4.  One accumulator per output and component, taps in
+// ascending order, every product and sum rounded (EXACT): the reference's summation, bit for bit.
+//
+// A chunk is LateGeom<L>::kChunkLen samples (960 | 1008): kMixLanes lanes replay the NCO and mix 16 consecutive samples each,
+// write them to LDS as rows of 3 L samples (row stride kStride: the b64 reads below are conflict-free), and lane l then
+// computes the three outputs k = base / L + 3 l + r from ONE pass over the 3 L - 1 + Nd samples that end in its row: window
+// sample u of lane l sits at l * kStride + const(u), the taps are wave-uniform scalars.  The last kCarryRows rows of a chunk
+// are the next chunk's history; the frame's last late_hist<L>() mixed samples are the next frame's (hb[]).
+template <bool EXACT, int LD>
+__device__ __forceinline__ void late_item(const K1Vfo *__restrict__ vfos, const K1Work W, unsigned long long frame_no, unsigned char *smem,
+                                          int lane)
+{
+    using G = LateGeom<LD>;
+    constexpr int N = G::kTaps, kRow = G::kRow, kStride = G::kStride, kHc = late_hist<LD>();
+    constexpr int kCarryElems = G::kCarryRows * kStride;
+    v2f *buf = reinterpret_cast<v2f *>(smem); // [(kCarryRows + kRows) * kStride]; sample p of the chunk (p >= -kHc) sits in row (p + kHc) / kRow
+    float *sh = reinterpret_cast<float *>(smem + late_window_bytes<LD>()); // the taps, zero-padded to kLateTapPad floats
+    const int par = (int)(frame_no & 1ull);
+    const K1Vfo *Dp = vfos + W.vfo;
+    struct {
+        const float2 *cp;
+        int n_in, L;
+    } D = {ldc(&Dp->cp), ldc(&Dp->n_in), ldc(&Dp->L)};
+    const v2f rot = {ldc(&Dp->rot_re), ldc(&Dp->rot_im)};
+    const float4 *in = reinterpret_cast<const float4 *>(ldc(&Dp->in[par]));
+    float2 *zout = ldc(&Dp->out[par]);
+    float2 *tap = ldc(&Dp->tap[par]);
+    const float2 *hist_load = ldc(&Dp->hb[par]);
+    float2 *hist_save = ldc(&Dp->hb[par ^ 1]);
+    const float *taps = ldc(&Dp->late_taps);
+    const v2f zero2 = {0.f, 0.f};
+
+    // history in front of the segment's first sample: the previous frame's last kHc mixed samples (zero at start-up,
+    // dsp.cpp:40-49), or zeros for a segment that starts inside the frame (its first kWarm samples are warm-up)
+    for (int t = lane; t < kHc; t += 64)
+        buf[(t / kRow) * kStride + t % kRow] = W.s_begin == 0 ? gldv2(hist_load + t) : zero2;
+    for (int t = lane; t < kLateTapPad; t += 64)
+        sh[t] = t < N ? gld(taps + t) : 0.f;
+    // where this lane's 16-sample run goes: it starts in row q0 at column r0 and crosses into row q0 + 1 at sample wr_T
+    const int q0 = (16 * lane) / kRow, r0 = 16 * lane - kRow * q0;
+    const int wr_lo = (G::kCarryRows + q0) * kStride + r0;
+    int wr_T = kRow - r0;
+    const v2f *rd = buf + lane * kStride; // window sample u of this lane: rd[(kCarryRows + floor(u / kRow)) * kStride + u mod kRow]
+    const int phase_frame = (int)((frame_no * (unsigned long long)D.n_in) % (unsigned long long)D.L);
+    int kb = W.s_begin / LD; // index of the first output of the chunk (s_begin is a multiple of L)
+    for (int base = W.s_begin; base < W.s_end; base += G::kChunkLen, kb += G::kChunkLen / LD) {
+        const int valid = min(G::kChunkLen, D.n_in - base);
+        // 1. this lane's run of 16 consecutive samples out of the parent's tile-layout stream.  (Lanes past the chunk or
+        //    the frame read on into the stream's spare tile: finite values nobody uses.)
+        const unsigned run = (unsigned)(base >> 4) + (unsigned)lane;
+        const float4 *src = in + ((run >> 6) * 512u + (run & 63u));
+        v2f x[kRun];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const v4f v = gldv4(src + 64 * i);
+            x[2 * i] = lo2(v);
+            x[2 * i + 1] = hi2(v);
+        }
+        // 2. NCO replay + mix, exactly as in mix_item (oscillator.cpp:20-28,39-50; vfo.cpp:241)
+        int idx = phase_frame + base; // both < L
+        idx -= idx >= D.L ? D.L : 0;
+        idx += lane * kRun;
+        idx -= idx >= D.L ? D.L : 0;
+        v2f o = gldv2(D.cp + (idx >> 4));
+        const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
+#pragma unroll
+        for (int i = 0; i < kRun; ++i) {
+            o = nco_step_pk(o, rot);
+            v2f m = o;
+            if (i == 0 && first_ever)
+                m = gldv2(D.cp + (D.L >> 4));
+            x[i] = cmul(m, x[i]);
+        }
+        if (tap && lane < G::kMixLanes && 16 * lane < valid && base + 16 * lane >= W.s_first_out) {
+            // decimate[0] is wanted (the GUI's spectrum tap, parity tests)
+            float4 *t4 = reinterpret_cast<float4 *>(tap + (size_t)(base + 16 * lane));
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                gstv4(t4 + i, cat2(x[2 * i], x[2 * i + 1]));
+        }
+        // 3. to LDS, rows of 3 L samples
+        wave_sync(); // the previous chunk's window reads and its carry rows are done
+        asm volatile("" : "+v"(wr_T)); // (16 selects per chunk instead of 16 addresses kept -- and spilled -- across the loop)
+        if (lane < G::kMixLanes) {
+#pragma unroll
+            for (int i = 0; i < kRun; ++i)
+                buf[wr_lo + i + (i >= wr_T ? kStride - kRow : 0)] = x[i];
+        }
+        wave_sync();
+        // 4. three outputs per lane from one pass over the window, a row of it at a time.  The taps come as broadcast b128
+        //    reads (the same address in every lane): as scalars they would be SGPR PAIRS (a packed instruction's scalar
+        //    operand is 64 bits wide), twice the SGPR file.  Window samples are read two at a time (b128) where the row
+        //    stride keeps pairs 16-byte aligned; single b64 reads otherwise.
+        if (lane < G::kRows) {
+            v2f acc[3] = {zero2, zero2, zero2};
+#pragma unroll
+            for (int fl = -G::kCarryRows; fl <= 0; ++fl) {
+                const int u_lo = kRow * fl < -N ? -N : kRow * fl, u_hi = kRow * (fl + 1) > 2 * LD ? 2 * LD : kRow * (fl + 1);
+                // taps this row touches: t = u - L r + N for u in [u_lo, u_hi), r in 0..2
+                const int t_lo = (u_lo + N - 2 * LD < 0 ? 0 : u_lo + N - 2 * LD) & ~3;
+                constexpr int kHv = (kRow + 2 * LD + 8) / 2;
+                v2f hv[kHv]; // tap PAIRS (t_lo + 2 q, + 1): a packed multiply takes either half for both of its lanes
+#pragma unroll
+                for (int g = 0; g < kHv / 2; ++g)
+                    if (t_lo + 4 * g < N && t_lo + 4 * g < u_hi + N) {
+                        const v4f q = *reinterpret_cast<const v4f *>(sh + t_lo + 4 * g);
+                        hv[2 * g] = lo2(q), hv[2 * g + 1] = hi2(q);
+                    }
+                const v2f *row = rd + (G::kCarryRows + fl) * kStride;
+                v2f w[kRow];
+#pragma unroll
+                for (int col = 0; col < kRow; ++col) {
+                    const int u = kRow * fl + col;
+                    if (u < u_lo || u >= u_hi)
+                        continue;
+                    const bool pairs = kStride % 2 == 0;
+                    if (pairs && col % 2 == 0 && col + 1 < kRow && u + 1 < u_hi) {
+                        const v4f q = *reinterpret_cast<const v4f *>(row + col);
+                        w[col] = lo2(q), w[col + 1] = hi2(q);
+                    } else if (!(pairs && col % 2 == 1 && u - 1 >= u_lo)) {
+                        w[col] = row[col];
+                    }
+                }
+#pragma unroll
+                for (int col = 0; col < kRow; ++col) {
+                    const int u = kRow * fl + col;
+                    if (u < u_lo || u >= u_hi)
+                        continue;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const int t = u - LD * r + N;
+                        if (t >= 0 && t < N) {
+                            const v2f hp = hv[(t - t_lo) >> 1];
+                            if ((t - t_lo) & 1)
+                                acc[r] = EXACT ? acc[r] + pk_mul_bcast<1>(hp, w[col], acc[r]) : pk_fma_bcast<1>(hp, w[col], acc[r]);
+                            else
+                                acc[r] = EXACT ? acc[r] + pk_mul_bcast<0>(hp, w[col], acc[r]) : pk_fma_bcast<0>(hp, w[col], acc[r]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0); // a row's reads stay in the row (all hoisted to the top they spill)
+            }
+            const int pos = base + kRow * lane; // input position L k of the lane's first output
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                if (pos + LD * r >= W.s_first_out && kRow * lane + LD * r < valid)
+                    gstv2_leaf(zout + (size_t)(kb + 3 * lane + r), acc[r]);
+        }
+        wave_sync();
+        if (base + valid == D.n_in) {
+            // the frame's last kHc mixed samples are the next frame's history (sample valid - kHc + t of this chunk)
+            for (int t = lane; t < kHc; t += 64) {
+                const int pp = valid + t;
+                gstv2(hist_save + t, buf[(pp / kRow) * kStride + pp % kRow]);
+            }
+        } else {
+            // the last kCarryRows rows become the next chunk's history rows
+            v2f c0 = zero2, c1 = zero2;
+            if (lane < kCarryElems)
+                c0 = buf[G::kRows * kStride + lane];
+            if (kCarryElems > 64 && lane + 64 < kCarryElems)
+                c1 = buf[G::kRows * kStride + lane + 64];
+            wave_sync();
+            if (lane < kCarryElems)
+                buf[lane] = c0;
+            if (kCarryElems > 64 && lane + 64 < kCarryElems)
+                buf[lane + 64] = c1;
+        }
+    }
+}
+
+// which body a work item runs: the fused late decimation for the leaves marked so at finalize, the half-band cascade otherwise
+template <bool EXACT>
+__device__ __forceinline__ void run_item(const K1Vfo *__restrict__ vfos, const K1Work W, unsigned long long frame_no,
+                                         const void *__restrict__ raw, int raw_mode, bool level0, unsigned char *smem, int lane)
+{
+    const int late = ldc(&vfos[W.vfo].late_L);
+    if (late == 5)
+        late_item<EXACT, 5>(vfos, W, frame_no, smem, lane);
+    else if (late == 6)
+        late_item<EXACT, 6>(vfos, W, frame_no, smem, lane);
+    else
+        mix_item<EXACT>(vfos, W, frame_no, raw, raw_mode, level0, smem, lane);
+}
+
 // One wave per workgroup, one workgroup per K1Work.  LEVEL only gives the root launch and the sub
 // launches distinct kernel names in profiles.
 template <bool EXACT, int LEVEL>
@@ -1129,7 +1348,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1
                                                      unsigned long long frame_no, const void *__restrict__ raw, int raw_mode)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    mix_item<EXACT>(vfos, work[blockIdx.x], frame_no, raw, raw_mode, LEVEL == 0, smem, (int)threadIdx.x);
+    run_item<EXACT>(vfos, work[blockIdx.x], frame_no, raw, raw_mode, LEVEL == 0, smem, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------ demod tail
@@ -1575,7 +1794,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_levels(const K1Vf
     if (it < 0)
         return;
     const int lv = ldc(item_level + it);
-    mix_item<EXACT>(k1, K1Work{ldc(&items[it].vfo), ldc(&items[it].s_begin), ldc(&items[it].s_first_out), ldc(&items[it].s_end)},
+    run_item<EXACT>(k1, K1Work{ldc(&items[it].vfo), ldc(&items[it].s_begin), ldc(&items[it].s_first_out), ldc(&items[it].s_end)},
                     A.frame_level[lv], A.raw, A.raw_mode, lv == 0, smem, (int)threadIdx.x);
 }
 

@@ -63,6 +63,8 @@ struct Node {
     size_t pay_off = 0; // into the payload buffer
     uint32_t pay_len = 0;
     float rot_re = 0, rot_im = 0;
+    int fused_late = 0;     // 5 | 6: the late decimation runs inside the mix wave (late_item); 0: not
+    bool has_stream = true; // decimate[d] of every frame is kept in HBM (false: a fused late decimation writes only z')
 };
 
 struct Launch1 { // one k_mix_decimate launch (a tree level)
@@ -110,7 +112,10 @@ struct sdrx_ctx {
     std::vector<Node> nodes;
     bool finalized = false;
     int opt_exact = 1, opt_prequant = 0, opt_segments = 0, opt_dc_blocked = 0, opt_pipeline = 0;
-    int opt_fuse = 1, opt_frame_pipeline = 1;
+    int opt_fuse = 1, opt_frame_pipeline = 1, opt_fuse_late = 1, opt_keep_streams = 0;
+    int tap_id = -1;                  // sdrx_set_tap: the node whose decimate[d] sdrx_get_stream is asked for
+    unsigned long long tap_since = 0; // first frame that keeps it
+    size_t tap_len = 0, off_tapbuf[2] = {0, 0}; // where a fused leaf keeps decimate[0] while it is the tap, per frame parity
     LevelPlan fp;
     std::vector<InFlight> pipe; // oldest first
     sdrx_publish_fn cb = nullptr;
@@ -658,6 +663,10 @@ int sdrx_set_option(sdrx_ctx *c, const char *name, int value)
         c->opt_fuse = value != 0;
     else if (!strcmp(name, "frame_pipeline"))
         c->opt_frame_pipeline = value != 0;
+    else if (!strcmp(name, "fuse_late"))
+        c->opt_fuse_late = value != 0;
+    else if (!strcmp(name, "keep_streams"))
+        c->opt_keep_streams = value != 0;
     else
         return fail(c, SDRX_EINVAL, "unknown option '%s'", name);
     return SDRX_OK;
@@ -737,33 +746,60 @@ int sdrx_set_publish_callback(sdrx_ctx *c, sdrx_publish_fn fn, void *user)
     return SDRX_OK;
 }
 
-static int finalize_impl(sdrx_ctx *c);
+} // extern "C"
 
-int sdrx_finalize(sdrx_ctx *c)
-{
-    if (!c)
-        return SDRX_EINVAL;
-    if (c->finalized)
-        return fail(c, SDRX_ESTATE, "sdrx_finalize called twice");
-    if (c->nodes.empty())
-        return fail(c, SDRX_ESTATE, "sdrx_finalize: no VFOs");
-    HIPCHK(c, hipSetDevice(c->device));
-    const int rc = finalize_impl(c);
-    if (rc != SDRX_OK) { // nothing of a half-built tree stays behind: a later call starts clean
-        (void)hipStreamSynchronize(c->stream);
-        free_device_state(c);
-        c->l1.clear();
-        c->lb.clear();
-        c->publish_order.clear();
+// ================================================================================ sdrx_finalize
+// = vfo::init for every node (vfo.cpp:60-176) plus everything the launches need, in phases that hand a `Built` to each
+// other: derive_nodes (rates, tap designs, tree levels, which leaves take the fused late decimation) -> plan_buffers (HBM
+// placement) -> build_mix_work (the (VFO, time segment) items of the mix/decimate launches) -> build_tail_work (the
+// block-per-tile launches of the leaf tail) -> build_level_plan (k_mix_levels' list) -> allocate_and_upload.
+namespace {
+
+struct Built { // host copies of what goes to the arena, and where
+    ArenaPlan plan;
+    std::map<std::vector<float>, size_t> tap_offsets; // identical tap sets are stored once
+    size_t pay = 0;                                   // bytes of the packed payload buffer
+    std::vector<std::vector<K1Work>> works;           // mix/decimate items per tree level
+    std::vector<int> level_count, level_maxd;
+    std::vector<K2aVfo> d2a;
+    std::vector<K2Vfo> d2;
+    std::vector<K3Vfo> d3;
+    std::vector<K4Vfo> d4;
+    std::vector<BlockWork> w2a, w2, w3, w4;
+    std::vector<int> n2a, n2, n3, n4; // node index of each descriptor
+    size_t o2a = 0, o2 = 0, o3 = 0, o4 = 0, ow2a = 0, ow2 = 0, ow3 = 0, ow4 = 0;
+    std::vector<K1Work> all_items; // k_mix_levels: every level's items in one array ...
+    std::vector<int> all_item_level, llist; // ... their levels, and the launch list over them
+    size_t off_nco_jobs = 0;
+
+    size_t place_taps(const std::vector<float> &t)
+    {
+        auto it = tap_offsets.find(t);
+        if (it != tap_offsets.end())
+            return it->second;
+        const size_t o = plan.take(t.size() * sizeof(float));
+        tap_offsets.emplace(t, o);
+        return o;
     }
-    return rc;
+};
+
+// Does this leaf run its /5 or /6 low-pass inside the mix wave (late_item)?  d = 0 below a parent (a tile-layout input),
+// and the tap count the geometry was laid out for -- which is what vfo::init's design formula yields at every rate.
+int fused_late_of(const sdrx_ctx *c, const Node &n)
+{
+    if (!c->opt_fuse_late || !n.leaf || !n.d.demod_usb || n.d.decimate_count != 0 || n.d.parent_id < 0)
+        return 0;
+    if (n.d.late_decimate == 5 && (int)n.dec.size() == LateGeom<5>::kTaps && n.d.samples_per_buffer >= LateGeom<5>::kChunkLen)
+        return 5;
+    if (n.d.late_decimate == 6 && (int)n.dec.size() == LateGeom<6>::kTaps && n.d.samples_per_buffer >= LateGeom<6>::kChunkLen)
+        return 6;
+    return 0;
 }
 
-static int finalize_impl(sdrx_ctx *c)
+// ---- per-node derived quantities: everything vfo::init computes (vfo.cpp:60-176)
+int derive_nodes(sdrx_ctx *c)
 {
     const int N = (int)c->nodes.size();
-
-    // ---- per-node derived quantities: everything vfo::init computes (vfo.cpp:60-176)
     c->root_frame = 0;
     int max_level = 0;
     for (int i = 0; i < N; ++i) {
@@ -776,12 +812,6 @@ static int finalize_impl(sdrx_ctx *c)
             if (rc != SDRX_OK)
                 return fail(c, rc, "vfo %d: %s", i, why);
         }
-        if (d.fs % kRun || d.samples_per_buffer % kRun || d.fs < kChunk)
-            return fail(c, SDRX_EUNSUPPORTED, "vfo %d: fs (%d) and samples_per_buffer (%d) must be multiples of 16 and fs >= 1024", i,
-                        d.fs, d.samples_per_buffer);
-        if (d.samples_per_buffer % (1 << d.decimate_count))
-            return fail(c, SDRX_EUNSUPPORTED, "vfo %d: samples_per_buffer %d not a multiple of 2^%d", i, d.samples_per_buffer,
-                        d.decimate_count);
         if (d.samples_per_buffer % kChunk != 0 && d.samples_per_buffer % kChunk < 256)
             return fail(c, SDRX_EUNSUPPORTED, "vfo %d: samples_per_buffer %d leaves a last chunk shorter than 256 samples", i,
                         d.samples_per_buffer);
@@ -845,66 +875,69 @@ static int finalize_impl(sdrx_ctx *c)
         max_level = std::max(max_level, n.level);
     }
     c->n_levels = max_level + 1;
+    for (Node &n : c->nodes)
+        n.fused_late = fused_late_of(c, n);
+    return SDRX_OK;
+}
 
-    // ---- arena plan
-    ArenaPlan plan;
-    std::map<std::vector<float>, size_t> tap_offsets; // identical tap sets are stored once
-    auto place_taps = [&](const std::vector<float> &t) -> size_t {
-        auto it = tap_offsets.find(t);
-        if (it != tap_offsets.end())
-            return it->second;
-        size_t o = plan.take(t.size() * sizeof(float));
-        tap_offsets.emplace(t, o);
-        return o;
-    };
+// ---- where everything lives in the arena; the payload buffer; SURVEY.md 8d's byte count
+void plan_buffers(sdrx_ctx *c, Built &B)
+{
+    const int N = (int)c->nodes.size();
+    ArenaPlan &plan = B.plan;
     c->off_k1vfo = plan.take(sizeof(K1Vfo) * (size_t)N);
-    size_t pay = 0;
     c->alg_bytes = 0;
     c->vfo_samples = 0;
-    c->mix_chunks = 0;
+    size_t tap_len = 0; // longest decimate[0] a fused leaf would have to keep (sdrx_set_tap)
     for (int i = 0; i < N; ++i) {
         Node &n = c->nodes[(size_t)i];
         const sdrx_vfo_desc &d = n.d;
         const bool late = d.demod_usb && d.late_decimate > 0;
         n.off_cp = plan.take(sizeof(float2) * (size_t)(d.fs / kRun + 1));
+        // half-band history -- or, for a fused late decimation, the previous frame's last mixed samples
+        const size_t hist = n.fused_late == 5 ? (size_t)late_hist<5>() : n.fused_late == 6 ? (size_t)late_hist<6>() : (size_t)std::max(1, d.decimate_count * kHbHist);
         for (int p = 0; p < 2; ++p)
-            n.off_hb[p] = plan.take(sizeof(float2) * (size_t)std::max(1, d.decimate_count * kHbHist));
+            n.off_hb[p] = plan.take(sizeof(float2) * hist);
         n.H = n.Hx = 0;
         if (n.leaf && d.demod_usb) {
             const int Hdemod = (int)align_up((size_t)((n.long_lpf ? 0 : n.lpf.size()) + 1 + kHilbert - 1), 4);
             if (late) {
-                n.Hx = (int)align_up(n.dec.size(), 4);
+                n.Hx = n.fused_late ? 0 : (int)align_up(n.dec.size(), 4);
                 n.H = Hdemod;
             } else {
                 n.Hx = Hdemod; // the stream itself feeds the demodulator
             }
         }
-        for (int p = 0; p < 2; ++p) // a stream that feeds children is kept in whole 1024-sample tiles
-            n.off_stream[p] = plan.take(sizeof(float2) * (n.leaf ? (size_t)(n.Hx + n.n_f) : align_up((size_t)n.n_f, kChunk) + kChunk)); // (+1 tile: a shifted walk's idle lanes read past the last one)
+        n.has_stream = !n.fused_late || c->opt_keep_streams;
+        if (n.has_stream)
+            for (int p = 0; p < 2; ++p) // a stream that feeds children is kept in whole 1024-sample tiles
+                n.off_stream[p] = plan.take(sizeof(float2) * (n.leaf ? (size_t)(n.Hx + n.n_f) : align_up((size_t)n.n_f, kChunk) + kChunk)); // (+1 tile: a shifted walk's idle lanes read past the last one)
+        else
+            tap_len = std::max(tap_len, (size_t)n.n_f);
         if (late)
             for (int p = 0; p < 2; ++p)
                 n.off_z[p] = plan.take(sizeof(float2) * (size_t)(n.H + n.n_out));
         if (!n.lpf_pad.empty())
-            n.off_lpf = place_taps(n.lpf_pad);
+            n.off_lpf = B.place_taps(n.lpf_pad);
         if (n.long_lpf) {
-            n.off_lpf = place_taps(n.lpf);
+            n.off_lpf = B.place_taps(n.lpf);
             n.Hu = (int)align_up(n.lpf.size(), 4);
             for (int p = 0; p < 2; ++p)
                 n.off_u[p] = plan.take(sizeof(float) * (size_t)(n.Hu + n.n_out));
         }
         if (!n.hnz.empty())
-            n.off_hnz = place_taps(n.hnz);
+            n.off_hnz = B.place_taps(n.hnz);
         if (!n.dec.empty())
-            n.off_dec = place_taps(n.dec);
+            n.off_dec = B.place_taps(n.dec);
         if (!n.hilbert.empty())
-            n.off_hilbert = place_taps(n.hilbert);
+            n.off_hilbert = B.place_taps(n.hilbert);
         if (n.leaf) {
-            n.pay_off = pay;
+            n.pay_off = B.pay;
             if (d.demod_usb)
                 n.pay_len = (uint32_t)(n.n_out * 2);
             else
                 n.pay_len = (uint32_t)(d.cstyle == 1 ? n.n_f : 2 * n.n_f); // vfo.cpp:143-150
-            pay = align_up(pay + n.pay_len, 64);
+            B.pay = align_up(B.pay + n.pay_len, 64);
             if (c->opt_prequant && d.demod_usb)
                 n.off_preq = plan.take(sizeof(float) * (size_t)n.n_out);
         }
@@ -912,13 +945,26 @@ static int finalize_impl(sdrx_ctx *c)
         c->alg_bytes += 8ll * d.samples_per_buffer + (n.leaf ? (int64_t)n.pay_len : 8ll * n.n_f);
         c->vfo_samples += d.samples_per_buffer;
     }
+    c->tap_len = tap_len;
+    for (int p = 0; p < 2; ++p)
+        c->off_tapbuf[p] = tap_len ? plan.take(sizeof(float2) * tap_len) : 0;
+}
 
-    // ---- work lists for k_mix_decimate, one launch per tree level
-    std::vector<std::vector<K1Work>> works((size_t)c->n_levels);
-    std::vector<int> level_count((size_t)c->n_levels, 0), level_maxd((size_t)c->n_levels, 0);
+// ---- work lists for the mix/decimate launches, one launch per tree level
+// A work item is one wave walking a run of chunks of one VFO-frame (+ a warm-up when it starts mid-frame).  Measured on
+// config 3 (profiles/README.md): the same NUMBER of segments for every VFO of a level, 32 work items per CU in total, in
+// VFO creation order (the long d=5 items of the first parent first, the short d=2 items of the second parent back-filling
+// the tail) beats one resident round of equal-length items (86 vs 91.5 us), equal-length short items (94-99 us),
+// class-interleaved order (103 us) and segment-major order (96-102 us).
+int build_mix_work(sdrx_ctx *c, Built &B)
+{
+    const int N = (int)c->nodes.size();
+    B.works.assign((size_t)c->n_levels, {});
+    B.level_count.assign((size_t)c->n_levels, 0);
+    B.level_maxd.assign((size_t)c->n_levels, 0);
     for (const Node &n : c->nodes) {
-        level_count[(size_t)n.level]++;
-        level_maxd[(size_t)n.level] = std::max(level_maxd[(size_t)n.level], n.d.decimate_count);
+        B.level_count[(size_t)n.level]++;
+        B.level_maxd[(size_t)n.level] = std::max(B.level_maxd[(size_t)n.level], n.d.decimate_count);
     }
     int ncu = 256;
     {
@@ -926,26 +972,24 @@ static int finalize_impl(sdrx_ctx *c)
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
             ncu = prop.multiProcessorCount;
     }
-    // Segmentation.  A work item is one wave walking a run of chunks of one VFO-frame (+ W warm-up
-    // chunks when it starts mid-frame).  Measured on config 3 (profiles/README.md): the same NUMBER
-    // of segments for every VFO of a level, 32 work items per CU in total, in VFO
-    // creation order (the long d=5 items of the first parent first, the short d=2 items of the
-    // second parent back-filling the tail) beats one resident round of equal-length items (86 vs
-    // 91.5 us), equal-length short items (94-99 us), class-interleaved order (103 us) and
-    // segment-major order (96-102 us).
     std::vector<int> level_nseg((size_t)c->n_levels, 1);
     for (int lv = 0; lv < c->n_levels; ++lv) // 32 work items per CU (= the hardware's wave slots per CU)
-        level_nseg[(size_t)lv] = std::max(1, (ncu * 32 + level_count[(size_t)lv] - 1) / level_count[(size_t)lv]);
+        level_nseg[(size_t)lv] = std::max(1, (ncu * 32 + B.level_count[(size_t)lv] - 1) / B.level_count[(size_t)lv]);
+    c->mix_chunks = 0;
     for (int i = 0; i < N; ++i) {
         const Node &n = c->nodes[(size_t)i];
         const int n_in = n.d.samples_per_buffer;
-        const int nchunks = (n_in + kChunk - 1) / kChunk;
-        const int warm = warmup_samples(n.d.decimate_count);
-        const int wch = (warm + kChunk - 1) / kChunk; // chunks a segment spends before its first exact output
+        // the walk's chunk and what a segment that starts inside the frame must walk before its first exact output:
+        // the half-band cascade's dependency cone, or the decimating low-pass's length (a multiple of 16 L: a segment of a
+        // fused late decimation starts on an output AND on a 16-sample run)
+        const int chunk = n.fused_late == 5 ? LateGeom<5>::kChunkLen : n.fused_late == 6 ? LateGeom<6>::kChunkLen : kChunk;
+        const int warm = n.fused_late == 5 ? LateGeom<5>::kWarm : n.fused_late == 6 ? LateGeom<6>::kWarm : warmup_samples(n.d.decimate_count);
+        const int nchunks = (n_in + chunk - 1) / chunk;
+        const int wch = (warm + chunk - 1) / chunk; // chunks a segment spends before its first exact output
         // few VFOs in the level (the 2-3 mains): segments as short as the warm-up allows;
-        // otherwise at least 4 chunks of useful work per segment
-        const bool few = (long long)level_count[(size_t)n.level] * nchunks < (long long)ncu * 16;
-        const int min_seg = few ? std::max(1, wch) : std::max(4, 4 * wch);
+        // otherwise at least 4 chunks of useful work per segment (2 where a chunk carries the low-pass as well)
+        const bool few = (long long)B.level_count[(size_t)n.level] * nchunks < (long long)ncu * 16;
+        const int min_seg = few ? std::max(1, wch) : n.fused_late ? 2 : std::max(4, 4 * wch);
         int nseg = c->opt_segments > 0 ? c->opt_segments : std::min(level_nseg[(size_t)n.level], std::max(1, nchunks / min_seg));
         nseg = std::max(1, std::min(nseg, nchunks / std::max(1, wch)));
         // Segment s > 0 starts `warm` samples before its first emitted output and ends on a chunk
@@ -956,8 +1000,8 @@ static int finalize_impl(sdrx_ctx *c)
         // < 4 % extra chunks): then segments stay tile aligned, which keeps the kernel's uniform
         // walk on the tiles (measured on the memory-bound flat workload: a walk that straddles two
         // tiles per chunk costs 5 %).
-        const bool shifted = (long long)(nseg - 1) * wch * 25 > nchunks;
-        const int lead = shifted ? warm : wch * kChunk; // samples a segment walks before its first emitted output
+        const bool shifted = n.fused_late || (long long)(nseg - 1) * wch * 25 > nchunks;
+        const int lead = shifted ? warm : wch * chunk; // samples a segment walks before its first emitted output
         const long long target = ((long long)n_in + nseg - 1) / nseg; // samples a segment should emit
         int first_out = 0;                                            // input position of the first output the next segment emits
         while (first_out < n_in) {
@@ -967,17 +1011,19 @@ static int finalize_impl(sdrx_ctx *c)
             w.s_begin = first_out == 0 ? 0 : first_out - lead;
             if (w.s_begin < 0)
                 return fail(c, SDRX_EUNSUPPORTED, "vfo %d: %d segments do not leave room for the %d-sample warm-up", i, nseg, warm);
-            long long k = ((long long)(first_out - w.s_begin) + target + kChunk / 2) / kChunk; // chunks of this segment's walk
-            k = std::max<long long>(k, lead / kChunk + 1);                                     // it must emit something
-            long long end = w.s_begin + k * kChunk;
-            if (end + lead + kChunk / 2 >= n_in) // what would be left is not worth a segment of its own
+            long long k = ((long long)(first_out - w.s_begin) + target + chunk / 2) / chunk; // chunks of this segment's walk
+            k = std::max<long long>(k, lead / chunk + 1);                                   // it must emit something
+            long long end = w.s_begin + k * chunk;
+            if (end + lead + chunk / 2 >= n_in) // what would be left is not worth a segment of its own
                 end = n_in;
             w.s_end = (int)std::min<long long>(n_in, end);
-            if (w.s_end == n_in && w.s_begin > 0) {
+            if (w.s_end == n_in && w.s_begin > 0 && !n.fused_late) {
                 // The chunk that holds the frame's last sample saves the filter history for the next
                 // frame from the registers of its last TWO lanes and from the tail of the LDS stages:
                 // like a tile-aligned frame (checked above), a shifted walk must end in a chunk of
                 // at least 256 samples.  Start earlier if it does not -- more warm-up is always exact.
+                // (A fused late decimation saves its history from LDS rows that hold the previous chunk's tail
+                // as well, and its first chunk is longer than that history: nothing to adjust.)
                 const int r = (n_in - w.s_begin) & (kChunk - 1);
                 if (r != 0 && r < 256) {
                     const int unit = std::max(16, 1 << n.d.decimate_count);
@@ -985,8 +1031,8 @@ static int finalize_impl(sdrx_ctx *c)
                     w.s_begin = std::max(0, w.s_begin - delta); // (0 = walk from the frame's start with the real history)
                 }
             }
-            works[(size_t)n.level].push_back(w);
-            c->mix_chunks += (w.s_end - w.s_begin + kChunk - 1) / kChunk;
+            B.works[(size_t)n.level].push_back(w);
+            c->mix_chunks += (w.s_end - w.s_begin + chunk - 1) / chunk;
             first_out = w.s_end;
         }
     }
@@ -995,7 +1041,7 @@ static int finalize_impl(sdrx_ctx *c)
     // SLOWER than keeping each VFO's -- and each parent's -- items together).
     if (const char *e = getenv("SDRX_ORDER")) {
         if (atoi(e) == 1) // segment-major: all first segments, then all second segments, ...
-            for (auto &wl : works)
+            for (auto &wl : B.works)
                 std::stable_sort(wl.begin(), wl.end(), [](const K1Work &a, const K1Work &b) { return a.s_first_out < b.s_first_out; });
     }
     c->l1.clear();
@@ -1003,55 +1049,58 @@ static int finalize_impl(sdrx_ctx *c)
         Launch1 L;
         L.kind = lv == 0 ? KIND_MIX_ROOT : KIND_MIX_SUB;
         L.level = lv;
-        L.n_work = (int)works[(size_t)lv].size();
+        L.n_work = (int)B.works[(size_t)lv].size();
         bool need_tr = false;
-        for (const Node &n : c->nodes)
-            need_tr |= n.level == lv && n.d.decimate_count == 0 && n.leaf;
-        L.lds_bytes = k1_lds_bytes(level_maxd[(size_t)lv], need_tr);
-        L.off_work = plan.take(sizeof(K1Work) * works[(size_t)lv].size());
+        int lds_late = 0;
         L.alg_bytes = 0;
-        for (const Node &n : c->nodes)
-            if (n.level == lv) // SURVEY.md 8d share of this launch: cf32 consumed (+ cf32 handed to children)
-                L.alg_bytes += 8ll * n.d.samples_per_buffer + (n.leaf ? 0ll : 8ll * n.n_f);
+        for (const Node &n : c->nodes) {
+            if (n.level != lv)
+                continue;
+            need_tr |= n.d.decimate_count == 0 && n.leaf && !n.fused_late;
+            lds_late = std::max(lds_late, n.fused_late == 5 ? late_lds_bytes<5>() : n.fused_late == 6 ? late_lds_bytes<6>() : 0);
+            // SURVEY.md 8d share of this launch: cf32 consumed (+ cf32 handed to children)
+            L.alg_bytes += 8ll * n.d.samples_per_buffer + (n.leaf ? 0ll : 8ll * n.n_f);
+        }
+        L.lds_bytes = std::max(k1_lds_bytes(B.level_maxd[(size_t)lv], need_tr), lds_late);
+        L.off_work = B.plan.take(sizeof(K1Work) * B.works[(size_t)lv].size());
         c->l1.push_back(L);
     }
+    return SDRX_OK;
+}
 
-    // ---- block-per-tile launches: one launch per kernel, driven by a (vfo, tile) work list
-    std::vector<K2aVfo> d2a;
-    std::vector<K2Vfo> d2;
-    std::vector<K3Vfo> d3;
-    std::vector<BlockWork> w2a, w2, w3;
-    std::vector<int> n2a, n2, n3; // node index of each descriptor
-    int64_t b2a = 0, b2 = 0, b3 = 0;
+// ---- block-per-tile launches of the leaf tail: one launch per kernel, driven by a (vfo, tile) work list
+void build_tail_work(sdrx_ctx *c, Built &B)
+{
+    const int N = (int)c->nodes.size();
+    int64_t b2 = 0, b3 = 0;
     int lds2a = 0;
-    // every late-decimating VFO has L in {5,6} and <= 96 taps: one-wave tiles, R outputs per lane
+    auto two_kernel_late = [](const Node &n) { return n.leaf && n.d.demod_usb && n.d.late_decimate > 0 && !n.fused_late; };
+    // every late-decimating VFO left to a kernel of its own has L in {5,6} and <= 96 taps: one-wave tiles, R outputs per lane
     bool late4 = !getenv("SDRX_NO_LATE4");
+    int late_lmax = 5, late_ndec = 0;
     for (const Node &n : c->nodes)
-        if (n.leaf && n.d.demod_usb && n.d.late_decimate > 0)
+        if (two_kernel_late(n)) {
             late4 = late4 && (n.d.late_decimate == 5 || n.d.late_decimate == 6) && (int)n.dec.size() <= kLateMaxTaps;
+            late_lmax = std::max(late_lmax, n.d.late_decimate);
+            late_ndec = std::max(late_ndec, (int)n.dec.size());
+        }
     c->late4 = late4;
     // 2 outputs per lane (8 KB of LDS per wave, ~20 waves per CU) measured 38 us on config 4, 4 outputs
     // per lane (fewer LDS reads, 16 KB, 10 waves per CU) 48 us, the one-output-per-thread kernel 54 us
     c->late4_r = getenv("SDRX_LATE4_R") ? atoi(getenv("SDRX_LATE4_R")) : 2;
     if (c->late4_r != 4)
         c->late4_r = 2;
-    int late_lmax = 5, late_ndec = 0;
-    for (const Node &n : c->nodes)
-        if (n.leaf && n.d.demod_usb && n.d.late_decimate > 0) {
-            late_lmax = std::max(late_lmax, n.d.late_decimate);
-            late_ndec = std::max(late_ndec, (int)n.dec.size());
-        }
     const int late_tile = late4 ? 64 * c->late4_r : 256;
     for (int i = 0; i < N; ++i) {
         Node &n = c->nodes[(size_t)i];
         if (!n.leaf)
             continue;
         if (n.d.demod_usb) {
-            if (n.d.late_decimate > 0) {
+            if (two_kernel_late(n)) {
                 for (int b = 0; b < (n.n_out + late_tile - 1) / late_tile; ++b)
-                    w2a.push_back({(int)d2a.size(), b});
-                n2a.push_back(i);
-                d2a.push_back(K2aVfo{});
+                    B.w2a.push_back({(int)B.d2a.size(), b});
+                B.n2a.push_back(i);
+                B.d2a.push_back(K2aVfo{});
                 lds2a = std::max(lds2a, (int)sizeof(float2) * (n.d.late_decimate * 255 + (int)n.dec.size()));
             }
             {
@@ -1062,119 +1111,116 @@ static int finalize_impl(sdrx_ctx *c)
                 n.demod_tile = (nl > 0 && !getenv("SDRX_DEMOD_FULL_TILE")) ? ((kDemodTile - (nl + (nl & 1))) & ~3) : kDemodTile;
             }
             for (int b = 0; b < (n.n_out + n.demod_tile - 1) / n.demod_tile; ++b)
-                w2.push_back({(int)d2.size(), b});
-            n2.push_back(i);
-            d2.push_back(K2Vfo{});
+                B.w2.push_back({(int)B.d2.size(), b});
+            B.n2.push_back(i);
+            B.d2.push_back(K2Vfo{});
             b2 += n.pay_len; // W_out of SURVEY.md 8d
+            if (n.long_lpf) {
+                for (int b = 0; b < (n.n_out + 255) / 256; ++b)
+                    B.w4.push_back({(int)B.d4.size(), b});
+                B.n4.push_back(i);
+                B.d4.push_back(K4Vfo{});
+            }
         } else {
             for (int b = 0; b < (n.n_f + 4095) / 4096; ++b)
-                w3.push_back({(int)d3.size(), b});
-            n3.push_back(i);
-            d3.push_back(K3Vfo{});
+                B.w3.push_back({(int)B.d3.size(), b});
+            B.n3.push_back(i);
+            B.d3.push_back(K3Vfo{});
             b3 += n.pay_len;
         }
     }
     c->lb.clear();
-    size_t o2a = 0, o2 = 0, o3 = 0, ow2a = 0, ow2 = 0, ow3 = 0;
-    if (!d2a.empty()) {
-        o2a = plan.take(sizeof(K2aVfo) * d2a.size());
-        ow2a = plan.take(sizeof(BlockWork) * w2a.size());
-        c->lb.push_back({KIND_LATE_DEC, (int)w2a.size(), o2a, ow2a, c->late4 ? late4_lds_bytes(c->late4_r, late_lmax, late_ndec) : lds2a, b2a});
+    ArenaPlan &plan = B.plan;
+    if (!B.d2a.empty()) {
+        B.o2a = plan.take(sizeof(K2aVfo) * B.d2a.size());
+        B.ow2a = plan.take(sizeof(BlockWork) * B.w2a.size());
+        c->lb.push_back({KIND_LATE_DEC, (int)B.w2a.size(), B.o2a, B.ow2a, c->late4 ? late4_lds_bytes(c->late4_r, late_lmax, late_ndec) : lds2a, 0});
     }
-    if (!d2.empty() && !getenv("SDRX_NO_LPT")) {
+    if (!B.d2.empty() && !getenv("SDRX_NO_LPT")) {
         // Blocks are independent and the launch is a few resident rounds deep, so its tail is set by
         // what is dispatched last: longest blocks first (a block with the audio low-pass does about
         // twice the work; the last block of a VFO-frame may be nearly empty).
         auto cost = [&](const BlockWork &b) {
-            const Node &n = c->nodes[(size_t)n2[(size_t)b.vfo]];
+            const Node &n = c->nodes[(size_t)B.n2[(size_t)b.vfo]];
             const int outs = std::min(n.demod_tile, n.n_out - b.blk * n.demod_tile);
             return (long long)outs * (kHilbertNz + (long long)(n.long_lpf ? 0 : n.lpf.size()));
         };
-        std::stable_sort(w2.begin(), w2.end(), [&](const BlockWork &a, const BlockWork &b) { return cost(a) > cost(b); });
+        std::stable_sort(B.w2.begin(), B.w2.end(), [&](const BlockWork &a, const BlockWork &b) { return cost(a) > cost(b); });
     }
-    if (!d2.empty()) {
-        o2 = plan.take(sizeof(K2Vfo) * d2.size());
-        ow2 = plan.take(sizeof(BlockWork) * w2.size());
-        c->lb.push_back({KIND_DEMOD, (int)w2.size(), o2, ow2, 0, b2});
+    if (!B.d2.empty()) {
+        B.o2 = plan.take(sizeof(K2Vfo) * B.d2.size());
+        B.ow2 = plan.take(sizeof(BlockWork) * B.w2.size());
+        c->lb.push_back({KIND_DEMOD, (int)B.w2.size(), B.o2, B.ow2, 0, b2});
     }
-    std::vector<K4Vfo> d4;
-    std::vector<BlockWork> w4;
-    std::vector<int> n4;
-    int lds4 = 0;
-    for (int i = 0; i < N; ++i) {
-        const Node &n = c->nodes[(size_t)i];
-        if (n.leaf && n.d.demod_usb && n.long_lpf) {
-            for (int b = 0; b < (n.n_out + 255) / 256; ++b)
-                w4.push_back({(int)d4.size(), b});
-            n4.push_back(i);
-            d4.push_back(K4Vfo{});
-            lds4 = std::max(lds4, (int)sizeof(float) * ((int)n.lpf.size() + 256));
-        }
+    if (!B.d4.empty()) {
+        int lds4 = 0;
+        for (int i : B.n4)
+            lds4 = std::max(lds4, (int)sizeof(float) * ((int)c->nodes[(size_t)i].lpf.size() + 256));
+        B.o4 = plan.take(sizeof(K4Vfo) * B.d4.size());
+        B.ow4 = plan.take(sizeof(BlockWork) * B.w4.size());
+        c->lb.push_back({KIND_LPF_LONG, (int)B.w4.size(), B.o4, B.ow4, lds4, 0});
     }
-    size_t o4 = 0, ow4 = 0;
-    if (!d4.empty()) {
-        o4 = plan.take(sizeof(K4Vfo) * d4.size());
-        ow4 = plan.take(sizeof(BlockWork) * w4.size());
-        c->lb.push_back({KIND_LPF_LONG, (int)w4.size(), o4, ow4, lds4, 0});
+    if (!B.d3.empty()) {
+        B.o3 = plan.take(sizeof(K3Vfo) * B.d3.size());
+        B.ow3 = plan.take(sizeof(BlockWork) * B.w3.size());
+        c->lb.push_back({KIND_COMPRESS, (int)B.w3.size(), B.o3, B.ow3, 0, b3});
     }
-    if (!d3.empty()) {
-        o3 = plan.take(sizeof(K3Vfo) * d3.size());
-        ow3 = plan.take(sizeof(BlockWork) * w3.size());
-        c->lb.push_back({KIND_COMPRESS, (int)w3.size(), o3, ow3, 0, b3});
-    }
-    // ---- the one-launch levels (k_mix_levels): unified item array and list
-    std::vector<K1Work> all_items;
-    std::vector<int> all_item_level, llist;
-    {
-        LevelPlan &P = c->fp;
-        P = LevelPlan();
-        P.usable = c->n_levels >= 2 && c->n_levels <= kMaxLevels; // (one level: nothing to share a launch with)
-        if (P.usable) {
-            // deepest level first: in the steady state of the reference's two-level trees the long sub-VFO
-            // items are dispatched first and the short level-0 items fill the launch's tail
-            // (SDRX_LEVEL_ORDER=1: level 0 first, for A/B runs)
-            const bool root_first = getenv("SDRX_LEVEL_ORDER") && atoi(getenv("SDRX_LEVEL_ORDER")) == 1;
-            P.part_begin.assign((size_t)c->n_levels, 0);
-            P.part_end.assign((size_t)c->n_levels, 0);
-            P.part_bytes.assign((size_t)c->n_levels, 0);
-            for (int q = 0; q < c->n_levels; ++q) {
-                const int lv = root_first ? q : c->n_levels - 1 - q;
-                while (llist.size() % 8)
-                    llist.push_back(-1);
-                P.part_begin[(size_t)lv] = (int)llist.size();
-                const int base = (int)all_items.size(), cnt = (int)works[(size_t)lv].size();
-                all_items.insert(all_items.end(), works[(size_t)lv].begin(), works[(size_t)lv].end());
-                all_item_level.insert(all_item_level.end(), (size_t)cnt, lv);
-                for (int i = 0; i < cnt; ++i)
-                    llist.push_back(base + i);
-                P.part_end[(size_t)lv] = (int)llist.size();
-                P.part_bytes[(size_t)lv] = c->l1[(size_t)lv].alg_bytes;
-                P.lds_bytes = std::max(P.lds_bytes, c->l1[(size_t)lv].lds_bytes);
-            }
-            P.off_items = plan.take(sizeof(K1Work) * all_items.size());
-            P.off_item_level = plan.take(sizeof(int) * all_item_level.size());
-            P.off_list = plan.take(sizeof(int) * llist.size());
-        }
-    }
-    const size_t off_nco_jobs = plan.take(sizeof(NcoInit) * (size_t)N);
+}
 
-    // ---- allocate, zero (= the reference's zero-initialised filter state, dsp.cpp:40-49), fill
-    c->arena_bytes = align_up(plan.size, 256);
+// ---- the one-launch levels (k_mix_levels): unified item array and list
+void build_level_plan(sdrx_ctx *c, Built &B)
+{
+    LevelPlan &P = c->fp;
+    P = LevelPlan();
+    P.usable = c->n_levels >= 2 && c->n_levels <= kMaxLevels; // (one level: nothing to share a launch with)
+    if (!P.usable)
+        return;
+    // deepest level first: in the steady state of the reference's two-level trees the long sub-VFO
+    // items are dispatched first and the short level-0 items fill the launch's tail
+    // (SDRX_LEVEL_ORDER=1: level 0 first, for A/B runs)
+    const bool root_first = getenv("SDRX_LEVEL_ORDER") && atoi(getenv("SDRX_LEVEL_ORDER")) == 1;
+    P.part_begin.assign((size_t)c->n_levels, 0);
+    P.part_end.assign((size_t)c->n_levels, 0);
+    P.part_bytes.assign((size_t)c->n_levels, 0);
+    for (int q = 0; q < c->n_levels; ++q) {
+        const int lv = root_first ? q : c->n_levels - 1 - q;
+        while (B.llist.size() % 8)
+            B.llist.push_back(-1);
+        P.part_begin[(size_t)lv] = (int)B.llist.size();
+        const int base = (int)B.all_items.size(), cnt = (int)B.works[(size_t)lv].size();
+        B.all_items.insert(B.all_items.end(), B.works[(size_t)lv].begin(), B.works[(size_t)lv].end());
+        B.all_item_level.insert(B.all_item_level.end(), (size_t)cnt, lv);
+        for (int i = 0; i < cnt; ++i)
+            B.llist.push_back(base + i);
+        P.part_end[(size_t)lv] = (int)B.llist.size();
+        P.part_bytes[(size_t)lv] = c->l1[(size_t)lv].alg_bytes;
+        P.lds_bytes = std::max(P.lds_bytes, c->l1[(size_t)lv].lds_bytes);
+    }
+    P.off_items = B.plan.take(sizeof(K1Work) * B.all_items.size());
+    P.off_item_level = B.plan.take(sizeof(int) * B.all_item_level.size());
+    P.off_list = B.plan.take(sizeof(int) * B.llist.size());
+}
+
+// ---- allocate, zero (= the reference's zero-initialised filter state, dsp.cpp:40-49), fill the descriptors, build the NCO tables
+int allocate_and_upload(sdrx_ctx *c, Built &B)
+{
+    const int N = (int)c->nodes.size();
+    B.off_nco_jobs = B.plan.take(sizeof(NcoInit) * (size_t)N);
+    c->arena_bytes = align_up(B.plan.size, 256);
     HIPCHK(c, hipMalloc(&c->arena, c->arena_bytes));
     HIPCHK(c, hipMemsetAsync(c->arena, 0, c->arena_bytes, c->stream));
-    c->pay_bytes = std::max<size_t>(pay, 64);
+    c->pay_bytes = std::max<size_t>(B.pay, 64);
     for (int p = 0; p < 2; ++p) {
         HIPCHK(c, hipMalloc(&c->d_pay[p], c->pay_bytes));
         HIPCHK(c, hipMemsetAsync(c->d_pay[p], 0, c->pay_bytes, c->stream));
         HIPCHK(c, hipHostMalloc(&c->h_pay[p], c->pay_bytes, hipHostMallocDefault));
         memset(c->h_pay[p], 0, c->pay_bytes);
     }
-
     {
         const size_t raw_tiles = align_up((size_t)c->root_frame, kChunk) + kChunk; // (+1 tile, as for the parents' streams)
         HIPCHK(c, hipMalloc(&c->d_raw_tiled, raw_tiles * sizeof(float2)));
         HIPCHK(c, hipMemsetAsync(c->d_raw_tiled, 0, raw_tiles * sizeof(float2), c->stream));
-        c->root_direct = level_count[0] <= 4 && !getenv("SDRX_NO_ROOT_DIRECT"); // the reference allows 3 mains (mainwindow.h:82)
+        c->root_direct = B.level_count[0] <= 4 && !getenv("SDRX_NO_ROOT_DIRECT"); // the reference allows 3 mains (mainwindow.h:82)
     }
     auto P = [&](size_t off) { return c->arena + off; };
     std::vector<K1Vfo> k1((size_t)N);
@@ -1190,7 +1236,12 @@ static int finalize_impl(sdrx_ctx *c)
             } else {
                 k.in[p] = c->d_raw_tiled;
             }
-            k.out[p] = reinterpret_cast<float2 *>(P(n.off_stream[p])) + n.Hx;
+            if (n.fused_late) { // the wave writes the decimated stream itself; decimate[0] only where it is kept
+                k.out[p] = reinterpret_cast<float2 *>(P(n.off_z[p])) + n.H;
+                k.tap[p] = n.has_stream ? reinterpret_cast<float2 *>(P(n.off_stream[p])) : nullptr;
+            } else {
+                k.out[p] = reinterpret_cast<float2 *>(P(n.off_stream[p])) + n.Hx;
+            }
             k.hb[p] = reinterpret_cast<float2 *>(P(n.off_hb[p]));
         }
         k.cp = reinterpret_cast<const float2 *>(P(n.off_cp));
@@ -1200,11 +1251,13 @@ static int finalize_impl(sdrx_ctx *c)
         k.d = n.d.decimate_count;
         k.L = n.d.fs;
         k.out_tiled = n.leaf ? 0 : 1;
+        k.late_L = n.fused_late;
+        k.late_taps = n.fused_late ? reinterpret_cast<const float *>(P(n.off_dec)) : nullptr;
         jobs[(size_t)i] = NcoInit{reinterpret_cast<float2 *>(P(n.off_cp)), n.rot_re, n.rot_im, n.d.fs, 0};
     }
-    for (size_t q = 0; q < d2a.size(); ++q) {
-        Node &n = c->nodes[(size_t)n2a[q]];
-        K2aVfo &k = d2a[q];
+    for (size_t q = 0; q < B.d2a.size(); ++q) {
+        Node &n = c->nodes[(size_t)B.n2a[q]];
+        K2aVfo &k = B.d2a[q];
         for (int p = 0; p < 2; ++p) {
             k.x[p] = reinterpret_cast<const float2 *>(P(n.off_stream[p]));
             k.x_next[p] = reinterpret_cast<float2 *>(P(n.off_stream[p ^ 1]));
@@ -1217,9 +1270,9 @@ static int finalize_impl(sdrx_ctx *c)
         k.L = n.d.late_decimate;
         k.n_out = n.n_out;
     }
-    for (size_t q = 0; q < d2.size(); ++q) {
-        Node &n = c->nodes[(size_t)n2[q]];
-        K2Vfo &k = d2[q];
+    for (size_t q = 0; q < B.d2.size(); ++q) {
+        Node &n = c->nodes[(size_t)B.n2[q]];
+        K2Vfo &k = B.d2[q];
         const bool late = n.d.late_decimate > 0;
         for (int p = 0; p < 2; ++p) {
             k.s[p] = reinterpret_cast<const float2 *>(P(late ? n.off_z[p] : n.off_stream[p]));
@@ -1238,9 +1291,9 @@ static int finalize_impl(sdrx_ctx *c)
         k.nlpf = n.long_lpf ? 0 : (int)n.lpf.size();
         k.tile = n.demod_tile;
     }
-    for (size_t q = 0; q < d4.size(); ++q) {
-        Node &n = c->nodes[(size_t)n4[q]];
-        K4Vfo &k = d4[q];
+    for (size_t q = 0; q < B.d4.size(); ++q) {
+        Node &n = c->nodes[(size_t)B.n4[q]];
+        K4Vfo &k = B.d4[q];
         for (int p = 0; p < 2; ++p) {
             k.u[p] = reinterpret_cast<const float *>(P(n.off_u[p]));
             k.u_next[p] = reinterpret_cast<float *>(P(n.off_u[p ^ 1]));
@@ -1253,9 +1306,9 @@ static int finalize_impl(sdrx_ctx *c)
         k.n = n.n_out;
         k.nlpf = (int)n.lpf.size();
     }
-    for (size_t q = 0; q < d3.size(); ++q) {
-        Node &n = c->nodes[(size_t)n3[q]];
-        K3Vfo &k = d3[q];
+    for (size_t q = 0; q < B.d3.size(); ++q) {
+        Node &n = c->nodes[(size_t)B.n3[q]];
+        K3Vfo &k = B.d3[q];
         for (int p = 0; p < 2; ++p) {
             k.s[p] = reinterpret_cast<const float2 *>(P(n.off_stream[p])) + n.Hx;
             k.pay[p] = reinterpret_cast<signed char *>(c->d_pay[p] + n.pay_off);
@@ -1268,40 +1321,43 @@ static int finalize_impl(sdrx_ctx *c)
         return bytes ? hipMemcpyAsync(P(off), src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
     };
     HIPCHK(c, up(c->off_k1vfo, k1.data(), sizeof(K1Vfo) * k1.size()));
-    HIPCHK(c, up(off_nco_jobs, jobs.data(), sizeof(NcoInit) * jobs.size()));
+    HIPCHK(c, up(B.off_nco_jobs, jobs.data(), sizeof(NcoInit) * jobs.size()));
     for (int lv = 0; lv < c->n_levels; ++lv)
-        HIPCHK(c, up(c->l1[(size_t)lv].off_work, works[(size_t)lv].data(), sizeof(K1Work) * works[(size_t)lv].size()));
-    HIPCHK(c, up(o2a, d2a.data(), sizeof(K2aVfo) * d2a.size()));
-    HIPCHK(c, up(ow2a, w2a.data(), sizeof(BlockWork) * w2a.size()));
-    HIPCHK(c, up(o2, d2.data(), sizeof(K2Vfo) * d2.size()));
-    HIPCHK(c, up(ow2, w2.data(), sizeof(BlockWork) * w2.size()));
-    HIPCHK(c, up(o4, d4.data(), sizeof(K4Vfo) * d4.size()));
-    HIPCHK(c, up(ow4, w4.data(), sizeof(BlockWork) * w4.size()));
-    HIPCHK(c, up(o3, d3.data(), sizeof(K3Vfo) * d3.size()));
-    HIPCHK(c, up(ow3, w3.data(), sizeof(BlockWork) * w3.size()));
+        HIPCHK(c, up(c->l1[(size_t)lv].off_work, B.works[(size_t)lv].data(), sizeof(K1Work) * B.works[(size_t)lv].size()));
+    HIPCHK(c, up(B.o2a, B.d2a.data(), sizeof(K2aVfo) * B.d2a.size()));
+    HIPCHK(c, up(B.ow2a, B.w2a.data(), sizeof(BlockWork) * B.w2a.size()));
+    HIPCHK(c, up(B.o2, B.d2.data(), sizeof(K2Vfo) * B.d2.size()));
+    HIPCHK(c, up(B.ow2, B.w2.data(), sizeof(BlockWork) * B.w2.size()));
+    HIPCHK(c, up(B.o4, B.d4.data(), sizeof(K4Vfo) * B.d4.size()));
+    HIPCHK(c, up(B.ow4, B.w4.data(), sizeof(BlockWork) * B.w4.size()));
+    HIPCHK(c, up(B.o3, B.d3.data(), sizeof(K3Vfo) * B.d3.size()));
+    HIPCHK(c, up(B.ow3, B.w3.data(), sizeof(BlockWork) * B.w3.size()));
     if (c->fp.usable) {
-        HIPCHK(c, up(c->fp.off_items, all_items.data(), sizeof(K1Work) * all_items.size()));
-        HIPCHK(c, up(c->fp.off_item_level, all_item_level.data(), sizeof(int) * all_item_level.size()));
-        HIPCHK(c, up(c->fp.off_list, llist.data(), sizeof(int) * llist.size()));
+        HIPCHK(c, up(c->fp.off_items, B.all_items.data(), sizeof(K1Work) * B.all_items.size()));
+        HIPCHK(c, up(c->fp.off_item_level, B.all_item_level.data(), sizeof(int) * B.all_item_level.size()));
+        HIPCHK(c, up(c->fp.off_list, B.llist.data(), sizeof(int) * B.llist.size()));
     }
-    for (auto &kv : tap_offsets)
+    for (auto &kv : B.tap_offsets)
         HIPCHK(c, up(kv.second, kv.first.data(), kv.first.size() * sizeof(float)));
-    HIPCHK(c, hipStreamSynchronize(c->stream)); // host vectors above go out of scope
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // the host vectors above go out of scope
 
-    // ---- NCO tables: Oscillator::Oscillator for every node, on the device
-    hipLaunchKernelGGL(k_nco_init, dim3((N + 63) / 64), dim3(64), 0, c->stream,
-                       reinterpret_cast<const NcoInit *>(P(off_nco_jobs)), N);
+    // NCO tables: Oscillator::Oscillator for every node, on the device
+    hipLaunchKernelGGL(k_nco_init, dim3((N + 63) / 64), dim3(64), 0, c->stream, reinterpret_cast<const NcoInit *>(P(B.off_nco_jobs)), N);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SDRX_OK;
+}
 
-    // ---- publish order: main VFOs in list order, their subs in list order (vfo.cpp:257-263)
+// ---- publish order: main VFOs in list order, their subs in list order (vfo.cpp:257-263)
+void build_publish_order(sdrx_ctx *c)
+{
     c->publish_order.clear();
     std::vector<int> stack;
-    for (int i = N - 1; i >= 0; --i)
+    for (int i = (int)c->nodes.size() - 1; i >= 0; --i)
         if (c->nodes[(size_t)i].d.parent_id < 0)
             stack.push_back(i);
     while (!stack.empty()) {
-        int i = stack.back();
+        const int i = stack.back();
         stack.pop_back();
         const Node &n = c->nodes[(size_t)i];
         if (n.leaf)
@@ -1310,7 +1366,83 @@ static int finalize_impl(sdrx_ctx *c)
             for (auto it = n.children.rbegin(); it != n.children.rend(); ++it)
                 stack.push_back(*it);
     }
+}
+
+int finalize_impl(sdrx_ctx *c)
+{
+    if (int rc = derive_nodes(c))
+        return rc;
+    Built B;
+    plan_buffers(c, B);
+    if (int rc = build_mix_work(c, B))
+        return rc;
+    build_tail_work(c, B);
+    build_level_plan(c, B);
+    if (int rc = allocate_and_upload(c, B))
+        return rc;
+    build_publish_order(c);
+    c->tap_id = -1;
     c->finalized = true;
+    return SDRX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int sdrx_finalize(sdrx_ctx *c)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    if (c->finalized)
+        return fail(c, SDRX_ESTATE, "sdrx_finalize called twice");
+    if (c->nodes.empty())
+        return fail(c, SDRX_ESTATE, "sdrx_finalize: no VFOs");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = finalize_impl(c);
+    if (rc != SDRX_OK) { // nothing of a half-built tree stays behind: a later call starts clean
+        (void)hipStreamSynchronize(c->stream);
+        free_device_state(c);
+        c->l1.clear();
+        c->lb.clear();
+        c->publish_order.clear();
+    }
+    return rc;
+}
+
+// The reference's fftVFOSlot(topic) (vfo.cpp:492-509): from the next frame on, decimate[decimateCount] of node `id` is what
+// sdrx_get_stream serves.  Every VFO keeps that stream in HBM anyway -- except a leaf whose late decimation runs inside the
+// mix wave (it writes only the decimated stream): for such a leaf this call makes the wave keep decimate[0] as well, one
+// leaf at a time.  id = -1: none.
+int sdrx_set_tap(sdrx_ctx *c, int id)
+{
+    if (!c)
+        return SDRX_EINVAL;
+    if (!c->finalized)
+        return fail(c, SDRX_ESTATE, "sdrx_set_tap before sdrx_finalize");
+    if (id < -1 || id >= (int)c->nodes.size())
+        return fail(c, SDRX_EINVAL, "bad vfo id %d", id);
+    if (c->in_flight > 0)
+        return fail(c, SDRX_ESTATE, "sdrx_set_tap: %d submitted frame(s) not yet delivered -- call sdrx_wait first", c->in_flight);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = drain(c)) // frames inside the software pipeline run to their end with the tap they were queued under
+        return rc;
+    auto set = [&](int node, bool on) -> hipError_t {
+        float2 *ptrs[2] = {nullptr, nullptr};
+        for (int p = 0; p < 2 && on; ++p)
+            ptrs[p] = reinterpret_cast<float2 *>(c->arena + c->off_tapbuf[p]);
+        return hipMemcpyAsync(c->arena + c->off_k1vfo + sizeof(K1Vfo) * (size_t)node + offsetof(K1Vfo, tap), ptrs, sizeof ptrs,
+                              hipMemcpyHostToDevice, c->stream);
+    };
+    auto needs_buffer = [&](int node) { return node >= 0 && !c->nodes[(size_t)node].has_stream; };
+    if (needs_buffer(c->tap_id) && c->tap_id != id)
+        HIPCHK(c, set(c->tap_id, false));
+    if (needs_buffer(id) && c->tap_id != id) {
+        HIPCHK(c, set(id, true));
+        c->tap_since = c->frame_no;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // (the two pointers above live on this call's stack)
+    c->tap_id = id;
     return SDRX_OK;
 }
 
@@ -1675,8 +1807,15 @@ int sdrx_get_stream(sdrx_ctx *c, int id, float *out, int max_complex, int *n_ret
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = drain(c))
         return rc;
+    if (!n.has_stream && !(c->tap_id == id && c->frame_no > c->tap_since))
+        return fail(c, SDRX_ESTATE,
+                    "sdrx_get_stream: vfo %d decimates by %d inside the mix wave and keeps no decimate[0] -- select it with sdrx_set_tap "
+                    "before the frame (the reference's fftVFOSlot), or set option keep_streams=1 / fuse_late=0",
+                    id, n.fused_late);
     if (out && cnt > 0) {
-        if (n.leaf) {
+        if (!n.has_stream) {
+            HIPCHK(c, hipMemcpy(out, c->arena + c->off_tapbuf[par], sizeof(float2) * (size_t)cnt, hipMemcpyDeviceToHost));
+        } else if (n.leaf) {
             HIPCHK(c, hipMemcpy(out, c->arena + n.off_stream[par] + sizeof(float2) * (size_t)n.Hx, sizeof(float2) * (size_t)cnt,
                                 hipMemcpyDeviceToHost));
         } else {

@@ -32,7 +32,48 @@ struct K1Vfo {
     int d;                 // half-band stages
     int L;                 // NCO table length = (int)fs
     int out_tiled;         // 1: children consume the output (tile layout); 0: natural order for the demod
+    // A leaf whose /5 or /6 low-pass (vfo::usb_decimdemod, vfo.cpp:334-387) runs in the mix wave itself (late_item, kernels.hip):
+    // d == 0, `out` = the DECIMATED stream z' (behind its demodulation history), hb[] = the last kLateHist mixed samples of
+    // the previous frame, and the mixed 240 kS/s stream decimate[0] is never written to HBM -- unless it is wanted:
+    int late_L;            // 0: not such a leaf; 5 | 6
+    int pad_;
+    const float *late_taps; // the Nd = LateGeom<L>::kTaps taps of the decimating low-pass
+    float2 *tap[2];        // non-null: also keep decimate[0] of this frame here, natural order (sdrx_set_tap, option keep_streams)
 };
+
+// Geometry of the fused late decimation for L in {5, 6}.  The decimating low-pass is low_pass(2, rate L, rate / 2, rate / (L - 1))
+// (vfo.cpp:82-87): its length (int)(53 fs / (22 tw)) made odd depends on fs / tw = L (L - 1) only -- 49 taps for L = 5, 73 for
+// L = 6, whatever the rate (checked at finalize; anything else takes the two-kernel path).  A wave walks its segment in chunks
+// of kChunkLen samples (a multiple of 16 L, so that a chunk starts on an output and a lane's 16-sample run on a run of the
+// tile layout) = kMixLanes lanes of 16 consecutive samples for the NCO and the mixer, and = kRows rows of 3 L samples for the
+// FIR: lane l then owns the three outputs whose newest-but-one sample lies in row l.
+template <int L>
+struct LateGeom;
+template <>
+struct LateGeom<5> {
+    static constexpr int kTaps = 49, kRow = 15, kRows = 64, kChunkLen = 960, kMixLanes = 60;
+    static constexpr int kStride = 18;    // LDS row stride in samples: 9 slots of 16 bytes -> the 16 lanes of a ds_read_b128 group hit 16 distinct slots,
+                                          //   and the 16 lanes of a ds_write_b64 group (pad 3: 6 dwords per row crossed) 16 distinct bank pairs
+    static constexpr int kCarryRows = 4;  // rows of the previous chunk a window reaches back into: 4 x 15 >= 49
+    static constexpr int kWarm = 80;      // a segment that starts inside the frame walks this many samples first: >= kTaps, a multiple of 16 L
+};
+template <>
+struct LateGeom<6> {
+    static constexpr int kTaps = 73, kRow = 18, kRows = 56, kChunkLen = 1008, kMixLanes = 63;
+    static constexpr int kStride = 19;    // 38 dwords
+    static constexpr int kCarryRows = 5;  // 5 x 18 >= 73
+    static constexpr int kWarm = 96;
+};
+template <int L>
+__host__ __device__ constexpr int late_hist() { return LateGeom<L>::kCarryRows * LateGeom<L>::kRow; } // samples carried between frames
+constexpr int kLateTapPad = 80; // the taps in LDS, zero-padded to whole float4s
+template <int L>
+__host__ __device__ constexpr int late_window_bytes() // [carry rows | chunk rows], rounded up to 16 bytes
+{
+    return (8 * (LateGeom<L>::kCarryRows + LateGeom<L>::kRows) * LateGeom<L>::kStride + 15) / 16 * 16;
+}
+template <int L>
+__host__ __device__ constexpr int late_lds_bytes() { return late_window_bytes<L>() + 4 * kLateTapPad; }
 
 // One wave's job: samples [s_begin, s_end) of one VFO-frame, walked in 1024-sample chunks (all three
 // are multiples of 16 and of 2^d; s_end - s_begin is a whole number of chunks except at the frame's

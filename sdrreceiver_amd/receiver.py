@@ -30,7 +30,8 @@ class Receiver:
     """One libsdrx context: a VFO tree on one GPU."""
 
     def __init__(self, device: int = 0, exact: bool = True, keep_prequant: bool = False, segments: int = 0,
-                 dc_blocked_scan: bool = False, pipeline: bool = False, fuse: bool = True, frame_pipeline: bool = True):
+                 dc_blocked_scan: bool = False, pipeline: bool = False, fuse: bool = True, frame_pipeline: bool = True,
+                 fuse_late: bool = True, keep_streams: bool = False):
         self.L = _lib.lib()
         h = C.c_void_p()
         rc = self.L.sdrx_create(C.byref(h), int(device))
@@ -48,6 +49,8 @@ class Receiver:
         self._chk(self.L.sdrx_set_option(self.h, b"pipeline", int(bool(pipeline))))
         self._chk(self.L.sdrx_set_option(self.h, b"fuse", int(bool(fuse))))
         self._chk(self.L.sdrx_set_option(self.h, b"frame_pipeline", int(bool(frame_pipeline))))
+        self._chk(self.L.sdrx_set_option(self.h, b"fuse_late", int(bool(fuse_late))))
+        self._chk(self.L.sdrx_set_option(self.h, b"keep_streams", int(bool(keep_streams))))
         self.finalized = False
 
     # -- plumbing -----------------------------------------------------------------
@@ -163,12 +166,22 @@ class Receiver:
         self._chk(self.L.sdrx_get_output(self.h, vid, None, None, C.byref(rate)))
         return rate.value
 
-    def stream(self, vid: int) -> np.ndarray:
+    def stream(self, vid: int, missing_ok: bool = False):
+        """decimate[decimateCount] of VFO `vid` after the last frame.  A leaf whose late decimation runs inside the
+        mix wave keeps it only while it is the tap (:meth:`set_tap`) or with ``keep_streams``: SdrxError otherwise,
+        or None with `missing_ok`."""
         n = C.c_int()
-        self._chk(self.L.sdrx_get_stream(self.h, vid, None, 0, C.byref(n)))
+        rc = self.L.sdrx_get_stream(self.h, vid, None, 0, C.byref(n))
+        if rc == _lib.SDRX_ESTATE and missing_ok and b"keeps no decimate[0]" in self.L.sdrx_last_error(self.h):
+            return None
+        self._chk(rc)
         out = np.zeros(2 * max(n.value, 1), np.float32)
         self._chk(self.L.sdrx_get_stream(self.h, vid, out.ctypes.data, n.value, C.byref(n)))
         return out[: 2 * n.value].view(np.complex64).copy()
+
+    def set_tap(self, vid: int) -> None:
+        """fftVFOSlot: from the next frame on :meth:`stream` serves VFO `vid` whatever its kind (-1: none)."""
+        self._chk(self.L.sdrx_set_tap(self.h, int(vid)))
 
     def raw(self) -> np.ndarray:
         """The raw frame as the main VFOs consumed it (after the byte LUT / DC-bias removal)."""
@@ -284,12 +297,14 @@ class Group:
         self._chk(self.L.sdrx_group_member(self.h, k, C.byref(ctx), C.byref(dev)))
         return ctx, dev.value
 
-    def stream(self, vid: int) -> np.ndarray:
+    def stream(self, vid: int, missing_ok: bool = False):
         """decimate[decimateCount] of VFO `vid` (an id of the whole tree) from the member that holds it."""
         m, lid = self.locate(vid)
         ctx, _ = self.member_context(m)
         n = C.c_int()
         rc = self.L.sdrx_get_stream(ctx, lid, None, 0, C.byref(n))
+        if rc == _lib.SDRX_ESTATE and missing_ok and b"keeps no decimate[0]" in self.L.sdrx_last_error(ctx):
+            return None
         if rc != 0:
             raise SdrxError(rc, self.L.sdrx_last_error(ctx).decode())
         out = np.zeros(2 * max(n.value, 1), np.float32)
@@ -393,6 +408,8 @@ class vfo:  # noqa: N801  (the reference's class name, vfo.h:11)
         """vfo.cpp:492-509: this VFO's decimate[decimateCount] goes to ``fftData`` after every
         frame while the selected topic is its own."""
         self.emitFFT = str(topic) == self.desc.topic
+        if self.emitFFT and self._radio is not None and self._radio.rx is not None:
+            self._radio.rx.set_tap(self._id)
 
     # observation, available once the owning sdrj has started
     def _r(self) -> Receiver:
@@ -470,6 +487,9 @@ class sdrj:  # noqa: N801  (the reference's class name, sdrj.h)
         for m in self.mains:
             add(m, -1)
         self.rx.finalize()
+        for v in self._all_vfos():  # a selection made before the tree existed (fftVFOSlot, vfo.cpp:492-509)
+            if v.emitFFT:
+                self.rx.set_tap(v._id)
 
     def demodData(self, data, length=None):
         if self.rx is None:

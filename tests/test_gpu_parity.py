@@ -36,7 +36,8 @@ def _frames(topo, n, seed=1, tones=None):
 
 def _check_exact(rx, nodes, topo, ctx):
     for i, v in enumerate(topo.vfos):
-        assert np.array_equal(bits(rx.stream(i)), bits(nodes[i].stream())), (ctx, i, "stream")
+        got = rx.stream(i, missing_ok=True)  # (None: a fused late decimation keeps no decimate[0]; its payload is checked)
+        assert got is None or np.array_equal(bits(got), bits(nodes[i].stream())), (ctx, i, "stream")
         if not topo.children(i):
             want = nodes[i].usb() if v.demod_usb else nodes[i].iq()
             assert np.array_equal(rx.output(i), want), (ctx, i, "payload")
@@ -45,9 +46,9 @@ def _check_exact(rx, nodes, topo, ctx):
 def _check_tolerance(rx, nodes, topo, ctx):
     for i, v in enumerate(topo.vfos):
         ref = nodes[i].stream()
-        got = rx.stream(i)
+        got = rx.stream(i, missing_ok=True)
         scale = float(np.abs(ref).max())
-        assert np.abs(got - ref).max() <= REL_TOL * scale, (ctx, i, "stream", np.abs(got - ref).max() / scale)
+        assert got is None or np.abs(got - ref).max() <= REL_TOL * scale, (ctx, i, "stream", np.abs(got - ref).max() / scale)
         if not topo.children(i) and v.demod_usb:
             pre_ref = nodes[i].usb_prequant()
             pre = rx.prequant(i).astype(np.float64)
@@ -95,27 +96,40 @@ def test_designed_taps_bit_exact(Receiver):
 
 
 # ------------------------------------------------------------------------------ whole chains
+# How a /5 or /6 leaf with decimate_count 0 runs (options "fuse_late", "keep_streams"): the default -- the decimating
+# low-pass inside the mix wave, decimate[0] never written --, the same keeping decimate[0] of every frame, and the
+# two-kernel form of rounds 1-3.  Results must not differ by one bit.
+LATE_MODES = {"fused": dict(), "fused+streams": dict(keep_streams=True), "two kernels": dict(fuse_late=False)}
+
+
+@pytest.mark.parametrize("late", sorted(LATE_MODES))
 @pytest.mark.parametrize("fixture", sorted(GOLDEN_TREES))
-def test_exact_mode_against_reference_fixtures(Receiver, fixture):
+def test_exact_mode_against_reference_fixtures(Receiver, fixture, late):
     """Default arithmetic vs the committed outputs of the real reference build: bit-identical
     payload and stream on every VFO and frame (crosses the NCO table wrap, > 1 s of signal)."""
     key, frames = GOLDEN_TREES[fixture]
     topo = golden_topology(key)
+    if late != "fused" and not any(v.late_decimate for v in topo.vfos):
+        pytest.skip("no late decimation in this tree")
     g = golden(fixture)
-    rx = Receiver.from_topology(topo, exact=True)
+    rx = Receiver.from_topology(topo, exact=True, **LATE_MODES[late])
     for f, iq in _frames(topo, frames):
         rx.process(iq)
         for i, v in enumerate(topo.vfos):
-            assert sha(rx.stream(i)) == str(g[f"f{f}_v{i}_stream_sha"]), (fixture, f, i)
+            s = rx.stream(i, missing_ok=late == "fused")
+            assert s is None or sha(s) == str(g[f"f{f}_v{i}_stream_sha"]), (fixture, f, i)
             if not topo.children(i):
                 assert sha(rx.output(i)) == str(g[f"f{f}_v{i}_pay_sha"]), (fixture, f, i)
     rx.close()
 
 
+@pytest.mark.parametrize("late", sorted(LATE_MODES))
 @pytest.mark.parametrize("key,frames", [("config1", 5), ("profile_25e", 5), ("54w", 3), ("288k", 6), ("compress", 2)])
-def test_exact_mode_against_live_oracle(Receiver, key, frames):
+def test_exact_mode_against_live_oracle(Receiver, key, frames, late):
     topo = golden_topology(key)
-    rx = Receiver.from_topology(topo, exact=True)
+    if late != "fused" and not any(v.late_decimate for v in topo.vfos):
+        pytest.skip("no late decimation in this tree")
+    rx = Receiver.from_topology(topo, exact=True, **LATE_MODES[late])
     nodes, roots = ob.build_tree("port", topo)
     for f, iq in _frames(topo, frames, seed=11, tones=[(-377000.0, 25.0), (251000.0, 11.0)]):
         rx.process(iq)
@@ -136,16 +150,69 @@ def test_fast_mode_within_tolerance(Receiver, key, frames):
     rx.close()
 
 
-def test_config4_256_vfos_vs_cpu(Receiver):
-    """BASELINE config 4: 1.92 MS/s, 3 mains, 256 late-decimate subs with the 10 kHz low-pass."""
+@pytest.mark.parametrize("late", sorted(LATE_MODES))
+def test_config4_256_vfos_vs_cpu(Receiver, late):
+    """BASELINE config 4: 1.92 MS/s, 3 mains, 256 late-decimate subs with the 10 kHz low-pass: every payload (and, where
+    decimate[0] is kept, every stream) of all 256 bit-identical to the oracle."""
     topo = tp.config4(256)
-    rx = Receiver.from_topology(topo, exact=True)
+    rx = Receiver.from_topology(topo, exact=True, **LATE_MODES[late])
     nodes, roots = ob.build_tree("port", topo)
     for f, iq in _frames(topo, 2, seed=2):
         rx.process(iq)
         ob.process_roots(roots, iq, threads=8)
-        _check_exact(rx, nodes, topo, ("config4", f))
+        _check_exact(rx, nodes, topo, ("config4", late, f))
     rx.close()
+
+
+def test_the_spectrum_tap_on_a_fused_late_decimation(Receiver):
+    """fftVFOSlot on the 54W tree: a /5 leaf whose low-pass runs inside the mix wave keeps decimate[0] only while it is
+    the tap (sdrx_set_tap), from the frame after the selection on; moving the tap moves the stream; every other stream
+    of the tree stays available; the payloads do not care."""
+    from sdrreceiver_amd.receiver import SdrxError
+    topo = golden_topology("54w")
+    fused = [i for i, v in enumerate(topo.vfos) if v.late_decimate and v.decimate_count == 0 and v.parent >= 0]
+    kept = [i for i in range(len(topo.vfos)) if i not in fused]
+    assert len(fused) >= 2 and kept
+    rx = Receiver.from_topology(topo, exact=True)
+    nodes, roots = ob.build_tree("port", topo)
+    frames = [iq for _, iq in _frames(topo, 6, seed=23, tones=[(700000.0, 30.0)])]
+    taps = [-1, fused[0], fused[0], fused[-1], kept[0], -1]  # selected BEFORE frame f
+    for f, iq in enumerate(frames):
+        rx.set_tap(taps[f])
+        rx.process(iq)
+        ob.process_roots(roots, iq)
+        for i in fused:
+            if i == taps[f]:
+                assert np.array_equal(bits(rx.stream(i)), bits(nodes[i].stream())), (f, i)
+            else:
+                with pytest.raises(SdrxError):
+                    rx.stream(i)
+        for i in kept:
+            assert np.array_equal(bits(rx.stream(i)), bits(nodes[i].stream())), (f, i)
+        for i in topo.leaves_in_publish_order():
+            want = nodes[i].usb() if topo.vfos[i].demod_usb else nodes[i].iq()
+            assert np.array_equal(rx.output(i), want), (f, i)
+    rx.close()
+
+
+@pytest.mark.parametrize("key", ["54w", "288k"])
+def test_time_segmentation_of_a_fused_late_decimation(Receiver, key):
+    """The /5 (960-sample chunks) and /6 (1008) walks cut into 1, 2, 5 and 13 segments per VFO-frame, each segment but
+    the first starting from zero history 80 / 96 samples early: not a bit changes, and it is the oracle's result."""
+    topo = golden_topology(key)
+    nodes, roots = ob.build_tree("port", topo)
+    frames = [iq for _, iq in _frames(topo, 3, seed=6, tones=[(333000.0, 12.0)])]
+    want = []
+    for iq in frames:
+        ob.process_roots(roots, iq)
+        want.append([(nodes[i].usb() if topo.vfos[i].demod_usb else nodes[i].iq()) for i in topo.leaves_in_publish_order()])
+    for seg in (1, 2, 5, 13):
+        rx = Receiver.from_topology(topo, exact=True, segments=seg, keep_streams=seg == 5)
+        for f, iq in enumerate(frames):
+            rx.process(iq)
+            for k, i in enumerate(topo.leaves_in_publish_order()):
+                assert np.array_equal(rx.output(i), want[f][k]), (key, seg, f, i)
+        rx.close()
 
 
 # ------------------------------------------------------------------------------ structure
@@ -795,7 +862,8 @@ def test_random_trees_against_the_oracle(Receiver):
         rng = np.random.default_rng(1000 + seed)
         topo = _random_topology(rng)
         try:
-            rx = Receiver.from_topology(topo, exact=True, segments=seed % 5, fuse=seed % 3 != 0)  # segments 0 = the library's own choice
+            rx = Receiver.from_topology(topo, exact=True, segments=seed % 5, fuse=seed % 3 != 0,  # segments 0 = the library's own choice
+                                        keep_streams=seed % 2 == 0, fuse_late=seed % 7 != 0)
         except SdrxError as e:
             assert "fs >= 1024" in str(e), (seed, str(e))
             continue
