@@ -12,6 +12,7 @@
 // Same client, same header, same ZmqPublisher: the message streams must be byte-identical.
 #include <QVector>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -162,8 +163,26 @@ int dropin_run(const sdrx_vfo_desc *descs, int n, const char *addr, int frames, 
             const float im = (float)((int)((x >> 24) % 17u) - 8);
             s = cpx_typef(re, im);
         }
-        for (vfo *m : mains) // sdrj.cpp:288-294
-            m->process(samples);
+        // DROPIN_MUTATE (test switch): bit 0 -- the samples CHANGE between two main VFOs' process() calls (same vector, same
+        // address; every 97th sample from the 7th on, sparing the 64 positions a spot check of the frame would look at);
+        // bit 1 -- on odd frames the first main VFO is not called at all.  Whatever `class vfo` sits behind the header must
+        // process what it is HANDED: an implementation that reuses an earlier upload of "the same" vector would not.
+        const int mutate = std::getenv("DROPIN_MUTATE") ? std::atoi(std::getenv("DROPIN_MUTATE")) : 0;
+        for (int mi = 0; mi < mains.size(); ++mi) { // sdrj.cpp:288-294
+            if ((mutate & 2) && mi == 0 && (frame_no & 1) && mains.size() > 1)
+                continue;
+            mains[mi]->process(samples);
+            if (mutate & 1) {
+                const size_t nf = 2 * samples.size();
+                for (size_t i = 7 + (size_t)mi; i < samples.size(); i += 97) {
+                    bool probe = false;
+                    for (size_t k = 0; k < 64 && !probe; ++k)
+                        probe = (k * (nf - 1) / 63) / 2 == i;
+                    if (!probe)
+                        samples[i] = cpx_typef(1.0f - samples[i].real(), samples[i].imag() + 2.0f);
+                }
+            }
+        }
         drain(300); // everything published for this frame (the first recv waits up to the timeout)
     }
     // MainWindow's stop: a vfo owns its children (vfo.cpp:49-57).  Before the subscriber goes: an implementation that

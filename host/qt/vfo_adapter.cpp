@@ -26,10 +26,11 @@
 // SDRX_DEVICES=<a,b,...>: the tree sharded over several GPUs of the node (sdrx_group_*).
 //
 // One upload per frame: sdrj::demodData hands every main VFO the SAME `samples` (sdrj.cpp:288-294).  The root that
-// is called first in a round uploads the frame; a root of another tree on the same device that is then called with
-// the same buffer (same address and length, not yet served from this upload, and a spot check of 64 values spread
-// over the frame agrees) runs on the uploaded copy (sdrx_process_shared): one PCIe crossing per frame instead of
-// one per main VFO.  SDRX_SHARE_UPLOAD=0 switches it off.
+// is called first uploads the frame; a root of another tree on the same device that is then called runs on that
+// uploaded copy (sdrx_process_if_same / sdrx_submit_if_same) if -- and only if -- its samples ARE the uploaded frame:
+// the library compares them byte for byte with the uploader's pinned staging copy (a memcmp of the frame instead of
+// its upload; no address or spot-check heuristics).  One PCIe crossing per frame instead of one per main VFO.
+// SDRX_SHARE_UPLOAD=0 switches it off.
 //
 // SDRX_PIPELINE=1: process() only SUBMITS its frame (sdrx_submit*) and delivers the PREVIOUS frame's payloads --
 // the frame's kernels and the payload copy of the one before run concurrently, 0.30 instead of 0.55 ms per frame
@@ -76,13 +77,9 @@ struct Tree {
     }
 };
 
-// The host frame most recently uploaded to a device by one of the trees (see "One upload per frame" above).
+// The tree that uploaded a host frame to a device last (see "One upload per frame" above).
 struct Upload {
     Tree *owner = nullptr;
-    const void *ptr = nullptr;
-    size_t n = 0;
-    float probe[64];
-    std::vector<const Tree *> served; // trees that have run on this upload (the owner included)
 };
 std::unordered_map<int, Upload> &uploads()
 {
@@ -90,11 +87,6 @@ std::unordered_map<int, Upload> &uploads()
     return *u;
 }
 int g_fft_taps = 0; // VFOs anywhere in the process with an fftData tap selected (vfo::fftVFOSlot)
-void take_probe(const float *iq, size_t n_floats, float *probe)
-{
-    for (size_t k = 0; k < 64; ++k)
-        probe[k] = iq[k * (n_floats - 1) / 63];
-}
 
 Tree::~Tree()
 {
@@ -380,39 +372,35 @@ void vfo::process(const std::vector<cpx_typef> &samples)
             T.tap = want;
         }
     }
-    // who uploads: this tree, unless another tree on the device already holds exactly this frame
-    sdrx_ctx *shared_from = nullptr;
-    if (T.ctx && n > 0 && !(std::getenv("SDRX_SHARE_UPLOAD") && std::atoi(std::getenv("SDRX_SHARE_UPLOAD")) == 0)) {
-        Upload &U = uploads()[T.device];
-        float probe[64];
-        take_probe(iq, (size_t)2 * n, probe);
-        const bool same = U.owner && U.owner != &T && U.owner->ctx && U.ptr == iq && U.n == (size_t)n &&
-                          std::find(U.served.begin(), U.served.end(), &T) == U.served.end() &&
-                          std::memcmp(probe, U.probe, sizeof probe) == 0;
-        if (same) {
-            shared_from = U.owner->ctx;
-            U.served.push_back(&T);
-        } else {
-            U.owner = &T;
-            U.ptr = iq;
-            U.n = (size_t)n;
-            std::memcpy(U.probe, probe, sizeof probe);
-            U.served.assign(1, &T);
-        }
-    }
+    // Who uploads: this tree -- unless the tree that uploaded last on this device holds exactly these samples (sdrj::demodData
+    // hands every main VFO the same vector, sdrj.cpp:288-294, but `class vfo` cannot know that): the library compares the
+    // caller's frame byte for byte with that tree's pinned staging copy (sdrx_*_if_same: a memcmp instead of an upload) and
+    // runs this tree on the frame already on the device only if they are equal.
+    const bool may_share = T.ctx && n > 0 && !(std::getenv("SDRX_SHARE_UPLOAD") && std::atoi(std::getenv("SDRX_SHARE_UPLOAD")) == 0);
+    Upload *U = may_share ? &uploads()[T.device] : nullptr;
+    sdrx_ctx *from = (U && U->owner && U->owner != &T) ? U->owner->ctx : nullptr;
+    bool shared = false;
     if (!T.pipelined) {
-        const int rc = T.grp ? sdrx_group_process(T.grp, iq, n) : shared_from ? sdrx_process_shared(T.ctx, shared_from) : sdrx_process(T.ctx, iq, n);
+        int rc = from ? sdrx_process_if_same(T.ctx, from, iq, n) : SDRX_DIFFERENT;
+        shared = rc == SDRX_OK;
+        if (rc == SDRX_DIFFERENT)
+            rc = T.grp ? sdrx_group_process(T.grp, iq, n) : sdrx_process(T.ctx, iq, n);
         if (rc != SDRX_OK)
             qFatal("sdrx adapter: sdrx_process: %s", T.error());
     } else {
         // submit(f); deliver f-1 -- or everything, while a spectrum tap wants this very frame's streams
-        const int rc = T.grp ? sdrx_group_submit(T.grp, iq, n) : shared_from ? sdrx_submit_shared(T.ctx, shared_from) : sdrx_submit(T.ctx, iq, n);
+        int rc = from ? sdrx_submit_if_same(T.ctx, from, iq, n) : SDRX_DIFFERENT;
+        shared = rc == SDRX_OK;
+        if (rc == SDRX_DIFFERENT)
+            rc = T.grp ? sdrx_group_submit(T.grp, iq, n) : sdrx_submit(T.ctx, iq, n);
         if (rc != SDRX_OK)
             qFatal("sdrx adapter: sdrx_submit: %s", T.error());
         ++T.in_flight;
         while (T.in_flight > (want_fft ? 0 : 1))
             T.deliver_one();
     }
+    if (U && !shared)
+        U->owner = &T; // (this tree's staging copy now holds the newest frame on the device)
     for (vfo *v : T.nodes) // vfo.cpp:290-293
         if (v->emitFFT) {
             int n = 0, id = side()[v].id;

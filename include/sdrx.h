@@ -184,6 +184,13 @@ int sdrx_submit_device(sdrx_ctx *ctx, const void *dev_iq, int n_complex);
  * shared frame stays valid until `src` stages the frame after next -- wait for it on `ctx` before that. */
 int sdrx_submit_shared(sdrx_ctx *ctx, sdrx_ctx *src);
 int sdrx_process_shared(sdrx_ctx *ctx, sdrx_ctx *src); /* = sdrx_submit_shared + sdrx_wait */
+/* The same for a binding that cannot KNOW that two main VFOs were handed the same samples (host/qt/vfo_adapter.cpp: `class
+ * vfo` only sees process(samples) calls): `iq` is compared byte for byte with the pinned staging copy of the frame `src`
+ * staged last (a memcmp of the frame instead of its upload).  Equal: exactly sdrx_submit_shared / sdrx_process_shared.  Not
+ * equal (or src staged bytes, not floats): SDRX_DIFFERENT (> 0), nothing queued -- submit the frame normally. */
+#define SDRX_DIFFERENT 1
+int sdrx_submit_if_same(sdrx_ctx *ctx, sdrx_ctx *src, const float *iq, int n_complex);
+int sdrx_process_if_same(sdrx_ctx *ctx, sdrx_ctx *src, const float *iq, int n_complex);
 int sdrx_wait(sdrx_ctx *ctx);
 int sdrx_in_flight(sdrx_ctx *ctx); /* >= 0: frames submitted and not yet delivered; < 0: error */
 

@@ -15,6 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PORT_SO = os.path.join(_HERE, "liborc.so")
 REF_SO = os.path.join(_HERE, "_ref", "libsdrref.so")
+REF_OFAST_SO = os.path.join(_HERE, "_ref", "libsdrref_ofast.so")  # the reference as shipped: -Ofast (SDRReceiver.pro:74-75)
 
 _vp, _i, _d, _f, _l = C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_long
 
@@ -45,10 +46,11 @@ class _Lib:
             build_port()
             self.lib = C.CDLL(PORT_SO)
             self.p = "orc_"
-        elif kind == "reference":
-            if not os.path.exists(REF_SO):
-                raise FileNotFoundError(REF_SO)
-            self.lib = C.CDLL(REF_SO)
+        elif kind in ("reference", "reference_ofast"):
+            so = REF_SO if kind == "reference" else REF_OFAST_SO
+            if not os.path.exists(so):
+                raise FileNotFoundError(so)
+            self.lib = C.CDLL(so)
             self.p = "ref_"
         else:
             raise ValueError(kind)
@@ -122,6 +124,10 @@ def load(kind: str = "port") -> _Lib:
 
 def have_reference() -> bool:
     return os.path.exists(REF_SO)
+
+
+def have_reference_ofast() -> bool:
+    return os.path.exists(REF_OFAST_SO)
 
 
 def _f32(a):

@@ -76,6 +76,8 @@ SYMBOLS = {
     "sdrx_get_nco": (_i, [_vp, _i, C.c_long, C.c_long, _vp]),
     "sdrx_submit_shared": (_i, [_vp, _vp]),
     "sdrx_process_shared": (_i, [_vp, _vp]),
+    "sdrx_submit_if_same": (_i, [_vp, _vp, _vp, _i]),
+    "sdrx_process_if_same": (_i, [_vp, _vp, _vp, _i]),
     "sdrx_group_create": (_i, [C.POINTER(_vp), C.POINTER(_i), _i]),
     "sdrx_group_destroy": (_i, [_vp]),
     "sdrx_group_last_error": (C.c_char_p, [_vp]),

@@ -144,6 +144,9 @@ struct sdrx_ctx {
                                            //   buffer stays untouched until f+2 is staged (another context on this device may
                                            //   be working on it: sdrx_submit_shared)
     hipEvent_t ev_staged[2] = {nullptr, nullptr}; // the host frame of parity p is complete on the device
+    // other contexts that ran on this context's uploaded frame of parity p (sdrx_submit_shared): each left an event behind its
+    // kernels, and this context's next upload into that buffer waits for them (events owned, and reused, by this context)
+    std::vector<hipEvent_t> shared_readers[2], reader_pool;
     float2 *d_raw_tiled = nullptr; // the raw frame in tile layout: input of the parent-less VFOs
     int last_raw = -1;             // how the last frame reached level 0 (kRaw*; -1: caller-owned device memory)
     bool late4 = false;            // k_late_decimate4 serves the late-decimation launch
@@ -631,6 +634,9 @@ int sdrx_destroy(sdrx_ctx *c)
     drain_events(c);
     for (hipEvent_t e : c->event_pool)
         (void)hipEventDestroy(e);
+    for (auto *v : {&c->reader_pool, &c->shared_readers[0], &c->shared_readers[1]})
+        for (hipEvent_t e : *v)
+            (void)hipEventDestroy(e);
     for (int p = 0; p < 2; ++p)
         for (hipEvent_t e : {c->ev_levels[p], c->ev_tail[p], c->ev_copied[p], c->ev_staged[p]})
             if (e)
@@ -1497,6 +1503,11 @@ int stage_host_frame(sdrx_ctx *c, const void *src, size_t bytes, void *dst_dev)
         c->h_in_bytes = (size_t)c->root_frame * sizeof(float2);
     }
     memcpy(c->h_in[p], src, bytes);
+    for (hipEvent_t e : c->shared_readers[p]) { // whoever shared frame f-2 of this buffer has read it before it is overwritten
+        HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
+        c->reader_pool.push_back(e);
+    }
+    c->shared_readers[p].clear();
     HIPCHK(c, hipMemcpyAsync(dst_dev, c->h_in[p], bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_staged[p], c->stream)); // (for a context that shares this frame: sdrx_submit_shared)
     return SDRX_OK;
@@ -1612,7 +1623,9 @@ int sdrx_submit_u8(sdrx_ctx *c, const uint8_t *bytes, int n_complex, int correct
 // every main VFO the same `samples` (sdrj.cpp:288-294) -- without a second host-to-device copy: `c` waits for
 // src's upload event and reads src's device buffer.  That buffer is per frame parity: it stays untouched until
 // `src` stages the frame after next, by which time the caller must have waited for this one on `c`.
-static int submit_shared(sdrx_ctx *c, sdrx_ctx *src, const char *what, bool sync_call)
+// `same_as` (may be null): host cf32 the caller believes to BE that frame -- compared byte for byte with src's pinned staging
+// copy first; SDRX_DIFFERENT and nothing queued when it is not.
+static int submit_shared(sdrx_ctx *c, sdrx_ctx *src, const char *what, bool sync_call, const float *same_as = nullptr, int same_n = 0)
 {
     if (!c || !src || c == src)
         return c ? fail(c, SDRX_EINVAL, "%s: needs another context as the source", what) : SDRX_EINVAL;
@@ -1621,6 +1634,11 @@ static int submit_shared(sdrx_ctx *c, sdrx_ctx *src, const char *what, bool sync
     if (src->device != c->device)
         return fail(c, SDRX_EINVAL, "%s: the source context lives on device %d, this one on %d", what, src->device, c->device);
     const int p = (int)((src->frame_no - 1) & 1ull);
+    if (same_as) {
+        if (src->last_raw != kRawF32 || same_n != src->root_frame || !src->h_in[p] ||
+            memcmp(src->h_in[p], same_as, (size_t)same_n * sizeof(float2)) != 0)
+            return SDRX_DIFFERENT;
+    }
     const void *frame = src->last_raw == kRawF32 ? (const void *)src->d_raw[p] : (const void *)src->d_raw_u8[p];
     int rc = check_frame_call(c, what, frame, src->root_frame, sync_call);
     if (rc)
@@ -1629,7 +1647,22 @@ static int submit_shared(sdrx_ctx *c, sdrx_ctx *src, const char *what, bool sync
         return fail(c, SDRX_EUNSUPPORTED, "%s: a wide level 0 (more than 4 parent-less VFOs) shares float frames only", what);
     HIPCHK(c, hipStreamWaitEvent(c->stream, src->ev_staged[p], 0));
     c->last_raw = -1; // (not this context's buffer: sdrx_get_raw is served by `src`)
-    return c->opt_exact ? enqueue_frame<true>(c, frame, src->last_raw, true) : enqueue_frame<false>(c, frame, src->last_raw, true);
+    const int src_raw = src->last_raw;
+    rc = c->opt_exact ? enqueue_frame<true>(c, frame, src_raw, true) : enqueue_frame<false>(c, frame, src_raw, true);
+    if (rc)
+        return rc;
+    // src's NEXT upload into this buffer (its frame after next) must not overtake these kernels: an event behind them, which
+    // src's staging waits for.  (With the documented calling order -- wait for this frame on `c` first -- it has long fired.)
+    hipEvent_t e = nullptr;
+    if (!src->reader_pool.empty()) {
+        e = src->reader_pool.back();
+        src->reader_pool.pop_back();
+    } else {
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    HIPCHK(c, hipEventRecord(e, c->stream));
+    src->shared_readers[p].push_back(e);
+    return SDRX_OK;
 }
 
 int sdrx_submit_shared(sdrx_ctx *c, sdrx_ctx *src) { return submit_shared(c, src, "sdrx_submit_shared", false); }
@@ -1637,6 +1670,21 @@ int sdrx_submit_shared(sdrx_ctx *c, sdrx_ctx *src) { return submit_shared(c, src
 int sdrx_process_shared(sdrx_ctx *c, sdrx_ctx *src)
 {
     const int rc = submit_shared(c, src, "sdrx_process_shared", true);
+    return rc ? rc : sdrx_wait(c);
+}
+
+int sdrx_submit_if_same(sdrx_ctx *c, sdrx_ctx *src, const float *iq, int n_complex)
+{
+    if (!iq)
+        return c ? fail(c, SDRX_EINVAL, "sdrx_submit_if_same: null frame pointer") : SDRX_EINVAL;
+    return submit_shared(c, src, "sdrx_submit_if_same", false, iq, n_complex);
+}
+
+int sdrx_process_if_same(sdrx_ctx *c, sdrx_ctx *src, const float *iq, int n_complex)
+{
+    if (!iq)
+        return c ? fail(c, SDRX_EINVAL, "sdrx_process_if_same: null frame pointer") : SDRX_EINVAL;
+    const int rc = submit_shared(c, src, "sdrx_process_if_same", true, iq, n_complex);
     return rc ? rc : sdrx_wait(c);
 }
 

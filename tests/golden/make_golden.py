@@ -152,6 +152,45 @@ def gen_chains():
     print("profile_288k.npz")
 
 
+OFAST_CASES = [("config1", 3), ("profile_25e", 3), ("54w", 2)]  # (tests/helpers.golden_topology key, frames)
+
+
+def gen_ofast():
+    """Outputs of the reference AS SHIPPED (-Ofast, SDRReceiver.pro:74-75; oracle/_ref/libsdrref_ofast.so) on the same
+    LCG frames as the -O2 fixtures.  -Ofast lets the compiler reassociate the filter sums, so these differ from the
+    canonical -O2 results in the last bits: per leaf and frame the fixture holds the int16 payload as a PATCH against
+    the -O2 payload (indices + values where the two builds differ, and the sha of the whole -Ofast payload: a checker
+    that holds the -O2 payload bit-exactly can rebuild the -Ofast one and prove it), and of every final complex
+    stream the first 256 samples, every 128th sample and max|z|."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import golden_topology
+    for key, frames in OFAST_CASES:
+        topo = golden_topology(key)
+        ref, fast = ob.build_tree("reference", topo), ob.build_tree("reference_ofast", topo)
+        lcg = synth.Lcg(1)
+        d = {"frames": np.int64(frames)}
+        ndiff = total = 0
+        for f in range(frames):
+            iq = synth.lcg_frame(topo.frame, lcg)
+            ob.process_roots(ref[1], iq)
+            ob.process_roots(fast[1], iq)
+            for i, v in enumerate(topo.vfos):
+                z = fast[0][i].stream()
+                d[f"f{f}_v{i}_stream_head"] = z[:256].copy()
+                d[f"f{f}_v{i}_stream_every128"] = z[::128].copy()
+                d[f"f{f}_v{i}_stream_absmax"] = np.float32(np.abs(z).max())
+                if not topo.children(i) and v.demod_usb:
+                    a, b = ref[0][i].usb(), fast[0][i].usb()
+                    idx = np.flatnonzero(a != b).astype(np.int32)
+                    d[f"f{f}_v{i}_pay_idx"] = idx
+                    d[f"f{f}_v{i}_pay_val"] = b[idx].copy()
+                    d[f"f{f}_v{i}_pay_sha"] = np.array(sha(b))
+                    ndiff += idx.size
+                    total += a.size
+        np.savez_compressed(os.path.join(OUT, f"ofast_{key}.npz"), **d)
+        print(f"ofast_{key}.npz: {ndiff} of {total} int16 samples differ from the -O2 build")
+
+
 def gen_zmq():
     """ZmqPublisher::publish framing through the real libzmq (ipc transport)."""
     import ctypes as C
@@ -196,9 +235,16 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dropin":
         gen_dropin()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ofast":
+        if not (ob.have_reference() and ob.have_reference_ofast()):
+            sys.exit("oracle/_ref/libsdrref.so / libsdrref_ofast.so missing: run `make -C oracle/ref` first (needs /root/reference)")
+        gen_ofast()
+        sys.exit(0)
     if not ob.have_reference():
         sys.exit("oracle/_ref/libsdrref.so missing: run `make -C oracle/ref` first (needs /root/reference)")
     gen_primitives()
     gen_chains()
     gen_zmq()
     gen_dropin()
+    if ob.have_reference_ofast():
+        gen_ofast()

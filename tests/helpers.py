@@ -70,3 +70,36 @@ def golden_topology(key):
     from sdrreceiver_amd import topology as tp
     return {"config1": tp.config1, "profile_25e": tp.profile_25e, "54w": topo_54w_golden,
             "compress": topo_compress_golden, "288k": topo_288k_golden}[key]()
+
+
+# ---- the reference AS SHIPPED (-Ofast, SDRReceiver.pro:74-75): tests/golden/ofast_*.npz ------------------------------
+OFAST_FIXTURES = {"ofast_config1.npz": "config1", "ofast_profile_25e.npz": "profile_25e", "ofast_54w.npz": "54w"}
+OFAST_REL_TOL = 1e-5  # north_star: "within 1e-5 relative float tolerance"
+
+
+def check_against_ofast_fixture(g, topo, f, stream_of, payload_of, o2_payload_of=None):
+    """Frame `f` of an implementation (`stream_of(i)` -> complex64 or None, `payload_of(i)` -> int16) against the -Ofast
+    fixture `g`: every final complex stream within 1e-5 of max|ref| at the stored positions (head + every 128th sample),
+    every int16 payload within +-1 LSB of the shipped build's.  The fixture holds that payload as a patch against the -O2
+    build's: `o2_payload_of(i)` must return the -O2 payload bit for bit (default: the implementation itself, i.e. it
+    claims to BE the -O2 result) -- patched, its sha must be the -Ofast payload's, which proves the reconstruction and,
+    for the default, that the implementation equals the shipped build everywhere outside the patch.
+    Returns (worst relative stream error, patched samples, payload samples)."""
+    worst, patched, total = 0.0, 0, 0
+    for i, v in enumerate(topo.vfos):
+        z = stream_of(i)
+        if z is not None:
+            scale = float(g[f"f{f}_v{i}_stream_absmax"])
+            e = max(float(np.abs(z[:256] - g[f"f{f}_v{i}_stream_head"]).max()), float(np.abs(z[::128] - g[f"f{f}_v{i}_stream_every128"]).max()))
+            assert e <= OFAST_REL_TOL * scale, (f, i, "stream", e / scale)
+            worst = max(worst, e / scale)
+        if not topo.children(i) and v.demod_usb:
+            got = payload_of(i)
+            shipped = (o2_payload_of(i) if o2_payload_of else got).copy()
+            idx, val = g[f"f{f}_v{i}_pay_idx"], g[f"f{f}_v{i}_pay_val"]
+            shipped[idx] = val
+            assert sha(shipped) == str(g[f"f{f}_v{i}_pay_sha"]), (f, i, "not the -Ofast payload: the -O2 payload it was rebuilt from is not bit-exact")
+            assert np.abs(got.astype(np.int32) - shipped.astype(np.int32)).max() <= 1, (f, i, "payload beyond 1 LSB of the shipped build")
+            patched += idx.size
+            total += got.size
+    return worst, patched, total

@@ -132,3 +132,31 @@ def test_adapter_pipelined_two_receivers_and_stop_start():
     assert len(got) == len(want)
     for g, w in zip(got, want):
         assert g == w
+
+
+def _raw(kind, name, frames, fft, env):
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "dropin_run.py"), kind, name, str(frames), fft],
+                                  text=True, timeout=600, env=dict(os.environ, **env))
+    return [json.loads(l) for l in out.splitlines()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [{}, {"SDRX_PIPELINE": "1"}])
+@pytest.mark.parametrize("mutate", ["1", "2", "3"])
+def test_adapter_processes_what_it_is_handed(mutate, mode):
+    """sdrj::demodData reuses one `samples` vector for every frame and every main VFO, so the address and the length of
+    what process() is handed never change.  Here the CONTENT changes between two main VFOs' calls (every 97th sample,
+    sparing the 64 positions the round-3 adapter spot-checked), and on odd frames the first main VFO -- the usual uploader
+    -- is skipped: the reference's `class vfo` processes what it is handed, and so must the adapter, whose second tree
+    shares the first one's upload only when the library has compared the two frames byte for byte (sdrx_*_if_same).
+    Both builds of the same client, same switch: byte-identical subscriber streams and fftData logs."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdropin_ref.so")):
+        pytest.skip("oracle/_ref/libdropin_ref.so not built (make -C host/qt needs /root/reference)")
+    env = {"DROPIN_MUTATE": mutate}
+    want = _raw("ref", "profile_25e", 4, "VFO19", env)
+    plain = _raw("ref", "profile_25e", 4, "VFO19", {})
+    assert want != plain  # (the switch does change what the reference publishes)
+    got = _raw("sdrx", "profile_25e", 4, "VFO19", dict(env, **mode))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g == w

@@ -138,6 +138,28 @@ def test_exact_mode_against_live_oracle(Receiver, key, frames, late):
     rx.close()
 
 
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("fixture", ["ofast_config1.npz", "ofast_profile_25e.npz", "ofast_54w.npz"])
+def test_against_the_reference_as_shipped(Receiver, fixture, exact):
+    """The reference's release build is -Ofast (SDRReceiver.pro:74-75); tests/golden/ofast_*.npz are its outputs (the -O2
+    build is the canonical oracle because -Ofast leaves the summation order to the compiler).  The HIP path, exact and
+    fast arithmetic, against them: every stream within 1e-5 of max|ref|, int16 audio within +-1 LSB -- and for the exact
+    arithmetic EQUAL to the shipped build's audio everywhere but at the samples where the two reference builds
+    themselves differ (2 / 120 / 66 of 9 000 / 657 000 / 156 000), proven by the sha of the whole -Ofast payload."""
+    from helpers import OFAST_FIXTURES, check_against_ofast_fixture
+    g = golden(fixture)
+    topo = golden_topology(OFAST_FIXTURES[fixture])
+    rx = Receiver.from_topology(topo, exact=exact, keep_streams=True)
+    nodes, roots = ob.build_tree("port", topo)  # (the fast arithmetic needs the -O2 payload to rebuild the shipped one from)
+    for f, iq in _frames(topo, int(g["frames"])):
+        rx.process(iq)
+        ob.process_roots(roots, iq)
+        worst, patched, total = check_against_ofast_fixture(g, topo, f, rx.stream, rx.output,
+                                                            o2_payload_of=None if exact else (lambda i: nodes[i].usb()))
+        assert worst < 2e-6 and patched * 1000 < total, (fixture, f, worst)
+    rx.close()
+
+
 @pytest.mark.parametrize("key,frames", [("config1", 5), ("profile_25e", 3), ("54w", 3), ("288k", 3)])
 def test_fast_mode_within_tolerance(Receiver, key, frames):
     topo = golden_topology(key)

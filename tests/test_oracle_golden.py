@@ -119,3 +119,18 @@ def test_double_to_short_wrap():
     f = L.fn("double_to_short")
     assert f(1009.99) == 1009 and f(-1009.99) == -1009 and f(32768.0) == -32768 and f(65537.5) == 1
     assert f(3e9) == 0 and f(float("nan")) == 0
+
+
+@pytest.mark.parametrize("fixture", ["ofast_config1.npz", "ofast_profile_25e.npz", "ofast_54w.npz"])
+def test_oracle_against_the_shipped_ofast_build(fixture):
+    """The plain-C oracle (= the -O2 reference, bit for bit) against the committed outputs of the reference as shipped
+    (-Ofast): streams within 1e-5, int16 within +-1 LSB and equal outside the fixture's patch."""
+    from helpers import OFAST_FIXTURES, check_against_ofast_fixture
+    g = golden(fixture)
+    topo = golden_topology(OFAST_FIXTURES[fixture])
+    nodes, roots = ob.build_tree("port", topo)
+    lcg = synth.Lcg(1)
+    for f in range(int(g["frames"])):
+        ob.process_roots(roots, synth.lcg_frame(topo.frame, lcg))
+        worst, patched, total = check_against_ofast_fixture(g, topo, f, lambda i: nodes[i].stream(), lambda i: nodes[i].usb())
+        assert worst < 1e-6 and patched * 1000 < total
