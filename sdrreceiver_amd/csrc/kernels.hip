@@ -277,108 +277,135 @@ __global__ __launch_bounds__(256) void k_ingest_u8(const unsigned *__restrict__ 
 // with an accumulator that lives for the whole process (function-static there; `state` here).
 // It is a true first-order recurrence in ROUNDED fp32 arithmetic -- fl(fl(avept*keep) + fl(k*curr)) -- so the
 // bit-exact form is sequential in the frame.  What IS sequential is two dependent VALU operations per sample and
-// component; everything else is not, and is kept off that chain: one workgroup of four waves walks the frame in
-// 1024-sample chunks as a three-stage pipeline over the chunks,
-//   waves 2-3  prepare chunk c+1: bytes -> floats -> fl(k*curr) for both components, into LDS;
-//   wave 0 / 1 run the I / the Q recurrence of chunk c: per 4 samples one broadcast ds_read_b128 of the prepared
-//              products, 4 x (v_mul, v_add) on a wave-uniform accumulator, one ds_write_b128 of the 4 estimates;
-//   waves 2-3  finish chunk c-1: curr - avept, stored in tile layout.
-// One __syncthreads() per chunk.  Measured: 4.5 ms per 384 000-sample frame (the one-wave version of rounds 1-2 took
-// 9.3 ms; the "1.7 ms" of the round-2 documents was an estimate).
-__global__ __launch_bounds__(256) void k_ingest_u8_dc(const unsigned *__restrict__ bytes4, float4 *__restrict__ tiled, int n_complex,
-                                                      float *__restrict__ state)
+// component, and on this machine a dependent v_mul_f32 -> v_add_f32 pair of a lone wave takes 12.25 cycles whatever
+// else is or is not going on (tools/dc_chain_probe.hip: one chain per wave 12.25 cycles per step; I and Q interleaved
+// in one wave 20.25 for the two; a DPP systolic form 20.25; a scalar operand costs nothing) -- while every OTHER
+// instruction the chain wave issues costs its ~4.5 cycles on top (the round-3 kernel's LDS traffic and register copies:
+// 24.6 cycles per sample).  So the chain gets a kernel in which it is nearly alone:
+//   k_dc_products   (parallel)  P[c][t] = fl(k * curr)                       all samples, both components
+//   k_dc_chain      (2 waves)   A[c][j] = avept before sample 16 j           wave c = component c, on a CU of its own; per 32
+//                                                                            samples two s_load_dwordx16 (the products arrive as
+//                                                                            scalar operands, a group ahead), the 64 chain
+//                                                                            operations, ONE 8-byte store
+//   k_dc_apply      (parallel)  replays the 16 steps behind each A[c][j], curr - avept, tile layout
+// Measured: 2.3 ms per 384 000-sample frame (4.5 ms for the one-workgroup pipeline of round 3, 9.3 ms for the one-wave
+// version of rounds 1-2); the floor of the recurrence itself is 384 000 x 12.25 cycles = 1.96 ms at 2.4 GHz.
+typedef float v16f __attribute__((ext_vector_type(16)));
+constexpr int kDcPad = 32 * 16 + 128; // floats behind the last sample of P / A: the chain's scalar prefetch runs two groups ahead, its line prefetch kDcAhead
+__global__ __launch_bounds__(256) void k_dc_products(const unsigned *__restrict__ bytes4, float *__restrict__ P, int n_complex, int stride)
 {
-    __shared__ __attribute__((aligned(16))) float sK[2][2][kChunk]; // fl(k * curr): [chunk parity][component][sample]
-    __shared__ __attribute__((aligned(16))) float sA[2][2][kChunk]; // avept after each sample
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const float keep = 1.0f - 0.000001f, k = 0.000001f;
-    const int nchunks = (n_complex + kChunk - 1) / kChunk;
-    float acc = wave < 2 ? state[wave] : 0.f; // wave-uniform: every lane of a chain wave carries the same value
-    for (int it = 0; it < nchunks + 2; ++it) {
-        if (wave >= 2) {
-            const int h = tid - 128; // 0..127
-            if (it < nchunks) { // prepare chunk `it`
-                const int base = it * kChunk, valid = min(kChunk, n_complex - base);
-                float(*K)[kChunk] = sK[it & 1];
+    const int w = blockIdx.x * 256 + threadIdx.x; // one word = 2 complex samples
+    if (2 * w >= n_complex)
+        return;
+    const float k = 0.000001f;
+    const unsigned u = bytes4[w];
+    const v2f pi = {k * (float)((int)(u & 255u) - 127), k * (float)((int)((u >> 16) & 255u) - 127)};
+    const v2f pq = {k * (float)((int)((u >> 8) & 255u) - 127), k * (float)((int)(u >> 24) - 127)};
+    *(SDRX_AS1 v2f *)(P + 2 * w) = pi;
+    *(SDRX_AS1 v2f *)(P + stride + 2 * w) = pq;
+}
+
+// 32 products as scalar operands: requested here, ARRIVED only behind dc_products_wait() (scalar loads return out of order:
+// nothing short of lgkmcnt(0) orders them).  The values the chain uses are the OUTPUTS of the wait, so no use of them can
+// be scheduled above it.  (`before`: a value whose further uses must come AFTER the request -- the accumulator: the chain
+// then cannot be scheduled above the loads it is meant to cover.)
+// The products were written by other CUs: a scalar load of them misses all the way to the Infinity Cache (~500 cycles, more
+// than the 392 cycles of chain a group of 32 samples covers).  So one VECTOR load per group touches the line kDcAhead groups
+// further on -- its result is never used and never waited for (another counter: vmcnt) -- and the scalar loads find their
+// lines in this XCD's L2.
+constexpr int kDcAhead = 16; // groups of 32 samples = 2 KiB
+// (`junk`: the register the line prefetches land in, some time after their issue and unknown to the compiler: one register,
+// handed through every request, so that it is never anything else's.)
+__device__ __forceinline__ void dc_products_request(v16f &lo, v16f &hi, const float *p, float &before, float &junk)
+{
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\tglobal_load_dword %2, %5, off"
+                 : "=s"(lo), "=s"(hi), "+v"(junk), "+v"(before)
+                 : "s"(p), "v"(p + 32 * kDcAhead));
+}
+__device__ __forceinline__ void dc_products_wait(v16f &lo, v16f &hi) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi)); }
+
+__device__ __forceinline__ float dc_block16(float acc, const v16f p)
+{
+    const float keep = 1.0f - 0.000001f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int w = h + 128 * q; // word = 2 complex samples
-                    const unsigned u = (2 * w < valid) ? bytes4[(base >> 1) + w] : 0x7f7f7f7fu;
-                    K[0][2 * w] = k * (float)((int)(u & 255u) - 127);
-                    K[1][2 * w] = k * (float)((int)((u >> 8) & 255u) - 127);
-                    K[0][2 * w + 1] = k * (float)((int)((u >> 16) & 255u) - 127);
-                    K[1][2 * w + 1] = k * (float)((int)(u >> 24) - 127);
-                }
-            }
-            if (it >= 2) { // finish chunk `it - 2`: subtract, tile layout
-                const int c = it - 2, base = c * kChunk, valid = min(kChunk, n_complex - base);
-                const float(*A)[kChunk] = sA[c & 1];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int unit = h + 128 * q, i2 = unit >> 6, ln = unit & 63;
-                    const int s0 = ln * kRun + 2 * i2;
-                    if (s0 < valid) {
-                        const unsigned u = bytes4[(base + s0) >> 1];
-                        float4 v = make_float4((float)((int)(u & 255u) - 127), (float)((int)((u >> 8) & 255u) - 127),
-                                               (float)((int)((u >> 16) & 255u) - 127), (float)((int)(u >> 24) - 127));
-                        v.x -= A[0][s0];
-                        v.y -= A[1][s0];
-                        v.z -= A[0][s0 + 1];
-                        v.w -= A[1][s0 + 1];
-                        tiled[tile_unit(c, i2, ln)] = v;
-                    }
-                }
-            }
-        } else if (it >= 1 && it <= nchunks) { // the recurrence of chunk `it - 1`, component `wave`
-            const int c = it - 1, valid = min(kChunk, n_complex - c * kChunk);
-            const float *K = sK[c & 1][wave];
-            float *A = sA[c & 1][wave];
-            // The products of the NEXT 16 samples are fetched while the chain works on the current 16 (an LDS latency per
-            // iteration would otherwise sit on the chain).  The optimiser sinks a plain load to its use in the next
-            // iteration, so the four ds_read_b128 are issued by hand and waited for after the chain.
-            const unsigned kaddr = (unsigned)(uintptr_t)K; // LDS byte address (the low half of the generic pointer)
-            v4f kq[4]; // (the same address in every lane: broadcast reads)
-            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
-                         "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(kq[0]), "=&v"(kq[1]), "=&v"(kq[2]), "=&v"(kq[3])
-                         : "v"(kaddr)
-                         : "memory");
-            for (int j = 0; j < valid; j += 16) { // frames are multiples of 16 samples
-                v4f kn[4];
-                const unsigned an = kaddr + 4u * (unsigned)min(j + 16, kChunk - 16);
-                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
-                             "ds_read_b128 %3, %4 offset:48"
-                             : "=&v"(kn[0]), "=&v"(kn[1]), "=&v"(kn[2]), "=&v"(kn[3])
-                             : "v"(an)
-                             : "memory");
-                float a[16];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    acc = acc * keep + kq[g].x;
-                    a[4 * g] = acc;
-                    acc = acc * keep + kq[g].y;
-                    a[4 * g + 1] = acc;
-                    acc = acc * keep + kq[g].z;
-                    a[4 * g + 2] = acc;
-                    acc = acc * keep + kq[g].w;
-                    a[4 * g + 3] = acc;
-                }
-                // the chain is done (its last value pinned) before the wait; the prefetched registers count as written here
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn[0]), "+v"(kn[1]), "+v"(kn[2]), "+v"(kn[3]), "+v"(acc)::"memory");
-                if (lane == 0) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<float4 *>(A + j + 4 * g) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    kq[g] = kn[g];
-            }
-        }
-        __syncthreads();
+    for (int i = 0; i < 16; ++i)
+        acc = acc * keep + p[i]; // -ffp-contract=off: v_mul_f32, v_add_f32 -- two roundings, like the reference's -O2 build
+    return acc;
+}
+
+// A[c][j] = avept BEFORE sample 16 j of component c: one value per 16 samples is all the chain wave stores (every store is
+// an instruction it issues on top of its chain); k_dc_apply replays the 16 steps behind each of them -- the same operations
+// on the same values, so the same bits -- in parallel.
+__global__ __launch_bounds__(64) void k_dc_chain(const float *__restrict__ P, float *__restrict__ A, int n_complex, int stride,
+                                                 float *__restrict__ state)
+{
+    if (threadIdx.x != 0) // the chain is one value: one lane computes and stores it (exec is set once, here)
+        return;
+    const int c = blockIdx.x; // component
+    const float *p = P + (size_t)c * stride;
+    float2 *a = reinterpret_cast<float2 *>(A + (size_t)c * (stride >> 4)); // (start of block 2 g, start of block 2 g + 1)
+    float acc = state[c];
+    const int ngrp = (n_complex + 31) >> 5; // groups of 32 samples (the last one may reach 16 samples into the padding behind the frame)
+    v16f c0, c1, n0, n1;
+    float junk = 0.f;
+    dc_products_request(c0, c1, p, acc, junk);
+    int g = 0;
+    for (; g + 1 < ngrp; g += 2) {
+        dc_products_wait(c0, c1);
+        dc_products_request(n0, n1, p + 32 * (g + 1), acc, junk);
+        float s0 = acc;
+        acc = dc_block16(acc, c0);
+        gst2(a + g, make_float2(s0, acc));
+        acc = dc_block16(acc, c1);
+        dc_products_wait(n0, n1);
+        dc_products_request(c0, c1, p + 32 * (g + 2), acc, junk); // (past the frame's end: the padding behind it)
+        s0 = acc;
+        acc = dc_block16(acc, n0);
+        gst2(a + g + 1, make_float2(s0, acc));
+        if (32 * (g + 1) + 16 < n_complex)
+            acc = dc_block16(acc, n1);
     }
-    if (wave < 2 && lane == 0)
-        state[wave] = acc;
+    dc_products_wait(c0, c1);
+    if (g < ngrp) {
+        const float s0 = acc;
+        acc = dc_block16(acc, c0);
+        gst2(a + g, make_float2(s0, acc));
+        if (32 * g + 16 < n_complex)
+            acc = dc_block16(acc, c1);
+    }
+    state[c] = acc;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(junk)); // the last line prefetches have landed: the register is free again
+}
+
+// curr - avept in tile layout: one thread = the 16 samples behind one stored estimate = one lane's run of a tile
+__global__ __launch_bounds__(256) void k_dc_apply(const unsigned *__restrict__ bytes4, const float *__restrict__ A, float4 *__restrict__ tiled,
+                                                  int n_complex, int stride)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x; // block of 16 samples
+    if (16 * j >= n_complex)
+        return;
+    const float keep = 1.0f - 0.000001f, k = 0.000001f;
+    float ai = A[j], aq = A[(stride >> 4) + j];
+    const v4u *src = reinterpret_cast<const v4u *>(bytes4) + 2 * j; // 32 bytes
+    const int ch = j >> 6, lane = j & 63;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const v4u q = gldv4u(src + h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned u = q[e];
+            const float x0 = (float)((int)(u & 255u) - 127), y0 = (float)((int)((u >> 8) & 255u) - 127);
+            const float x1 = (float)((int)((u >> 16) & 255u) - 127), y1 = (float)((int)(u >> 24) - 127);
+            ai = ai * keep + k * x0;
+            aq = aq * keep + k * y0;
+            float4 v;
+            v.x = x0 - ai, v.y = y0 - aq;
+            ai = ai * keep + k * x1;
+            aq = aq * keep + k * y1;
+            v.z = x1 - ai, v.w = y1 - aq;
+            tiled[tile_unit(ch, 4 * h + e, lane)] = v;
+        }
+    }
 }
 
 // The fast-arithmetic form of the same DC-bias removal (option "exact" = 0): the recurrence is

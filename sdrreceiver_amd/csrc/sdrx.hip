@@ -154,6 +154,8 @@ struct sdrx_ctx {
     bool root_direct = false;      // level 0 reads the caller's natural-order frame itself (few VFOs)
     unsigned char *d_raw_u8[2] = {nullptr, nullptr}; // the same for dongle bytes
     float *d_dc_state = nullptr;   // DC-bias accumulator (exact: [2]; fast: [parity][2])
+    float *d_dc_work = nullptr;    // exact DC-bias removal: products P[2][stride] and estimates A[2][stride] of one frame
+    int dc_work_stride = 0;
     double *d_dc_tab = nullptr;    // fast DC scan: powers of the decay + per-chunk sums behind them
     unsigned long long dc_frames = 0; // frames the fast scan has run on (its state ping-pongs)
     size_t dc_tab_sums = 0;        // offset (in doubles) of the double2 sums[] inside d_dc_tab
@@ -537,6 +539,8 @@ void free_device_state(sdrx_ctx *c)
     }
     dfree(c->d_raw_tiled);
     dfree(c->d_dc_state);
+    dfree(c->d_dc_work);
+    c->dc_work_stride = 0;
     dfree(c->d_dc_tab);
     c->raw_cap = 0;
 }
@@ -1553,9 +1557,24 @@ int enqueue_u8_device(sdrx_ctx *c, const void *dev_bytes, int n_complex, int cor
         HIPCHK(c, hipMemcpy(c->d_dc_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if (correct_dc && !c->opt_dc_blocked) {
+        // products (parallel) -> the two recurrences (one wave each, nearly alone with their dependent chain) -> subtract (parallel)
+        const int stride = (int)align_up((size_t)n_complex + kDcPad, 64);
+        if (c->dc_work_stride < stride) {
+            if (c->d_dc_work)
+                (void)hipFree(c->d_dc_work);
+            c->d_dc_work = nullptr;
+            HIPCHK(c, hipMalloc(&c->d_dc_work, sizeof(float) * 4 * (size_t)stride)); // P[2][stride] | A[2][stride]
+            HIPCHK(c, hipMemsetAsync(c->d_dc_work, 0, sizeof(float) * 4 * (size_t)stride, c->stream));
+            c->dc_work_stride = stride;
+        }
+        float *Pp = c->d_dc_work, *Ap = c->d_dc_work + 2 * (size_t)c->dc_work_stride;
+        const int words = n_complex / 2;
         Bracket b(c, c->stream, KIND_INGEST, 0);
-        hipLaunchKernelGGL(k_ingest_u8_dc, dim3(1), dim3(256), 0, c->stream, reinterpret_cast<const unsigned *>(dev_bytes),
-                           reinterpret_cast<float4 *>(c->d_raw_tiled), n_complex, c->d_dc_state);
+        hipLaunchKernelGGL(k_dc_products, dim3((words + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const unsigned *>(dev_bytes), Pp,
+                           n_complex, c->dc_work_stride);
+        hipLaunchKernelGGL(k_dc_chain, dim3(2), dim3(64), 0, c->stream, Pp, Ap, n_complex, c->dc_work_stride, c->d_dc_state);
+        hipLaunchKernelGGL(k_dc_apply, dim3((words + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const unsigned *>(dev_bytes), Ap,
+                           reinterpret_cast<float4 *>(c->d_raw_tiled), n_complex, c->dc_work_stride);
         mode = kRawTiled;
     } else if (correct_dc) {
         Bracket b(c, c->stream, KIND_INGEST, 0);
