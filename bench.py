@@ -141,15 +141,43 @@ def build_id():
         return "unknown"
 
 
-def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix_chunks):
-    """SURVEY.md 8d's contract figure (algorithmic bytes / launch duration vs 8 TB/s) plus what the
-    counters say actually bounds the launch: real HBM traffic, L2 hit rate, VALU issue."""
+def demanded_valu_per_launch(topo):
+    """VALU wave-instructions the reference's arithmetic, done in its order, demands of ONE steady-state launch of the
+    mix/decimate items (one frame's worth of every VFO): per 1024-sample chunk NCO replay 16 x 7 + mix 16 x 3, stage 0
+    8 x 11 + 16 halo moves, stage 1 4 x 11 + 16, an 11-instruction dot product per 64 outputs of every deeper stage
+    (tools/inst_mix.py checks these counts against the compiled ISA); per 960 / 1008-sample chunk of a fused late
+    decimation NCO + mix and 3 x Nd x 2 for the decimating low-pass.  Addressing, loop control, warm-up: not demanded."""
+    total = 0
+    for v in topo.vfos:
+        n, d = v.samples_per_buffer, v.decimate_count
+        if v.demod_usb and v.late_decimate in (5, 6) and d == 0 and v.parent >= 0:
+            chunk, taps = (960, 49) if v.late_decimate == 5 else (1008, 73)
+            total += -(-n // chunk) * (16 * 10 + 3 * taps * 2)
+            continue
+        per = 16 * 10
+        if d >= 1:
+            per += 8 * 11 + 16
+        if d >= 2:
+            per += 4 * 11 + 16
+        for s_ in range(2, d):
+            per += 11 * max(1, (1024 >> (s_ + 1)) // 64)
+        total += -(-n // 1024) * per
+    return total
+
+
+def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix_chunks, demanded=None):
+    """The dominant launch against the bound that binds it.
+    `bound` / `achieved` / `peak` / `unit` / `frac` are those of the LIMITER the counters name (a fraction by construction):
+    "hbm" -- counter bytes (what really crossed the L2 <-> fabric boundary) per second against 8 TB/s -- or "valu" -- VALU
+    issue slots carrying an instruction against what a saturated probe of the same instruction mix sustains.
+    SURVEY.md 8d's contract figure (ALGORITHMIC bytes -- 8 n_in for EVERY sibling although they share one parent stream
+    through L2 -- over the launch duration) is `algorithmic_GBps` / `algorithmic_over_hbm_peak`: it may exceed 1 and is not
+    called a fraction."""
     dom_bytes = d["alg_bytes"] / d["launches"]
     dom_avg_s = d["ms"] / d["launches"] * 1e-3
-    achieved = dom_bytes / dom_avg_s / 1e9
-    # (`bound` is the roofline the contract prices against; what binds the launch is `limiter`, from the counters)
-    r = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+    alg = dom_bytes / dom_avg_s / 1e9
+    r = {"bound": None, "kernel": dom, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "traffic_source": None,
+         "algorithmic_GBps": round(alg, 1), "algorithmic_over_hbm_peak": round(alg / HBM_PEAK_GBS, 4),
          "bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 5),
          "frame_kernel_ms": round(frame_kernel_ms, 5),
          "frame_frac": round(alg_bytes / world / (frame_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -157,21 +185,22 @@ def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix
     if not k:
         r["limited_by"] = "unknown here: no committed PMC passes for this workload (tools/profile.sh)"
         return r
-    cn = k.get("counters", {})
     r["traffic_source"] = pm.get("source")
     r["pmc_git_sha"] = pm.get("git_sha")
-    # the counter passes name the library they measured (sdrx_build_id, a hash of the kernel / host sources): a mismatch
-    # means the committed counters are from an older build than the one timed here
+    # the counter passes name the library they measured (sdrx_build_id, a hash of the sources and flags): a mismatch
+    # means the committed counters are from another build than the one timed here
     r["pmc_build_id"] = pm.get("build_id")
     r["pmc_matches_build"] = (pm.get("build_id") == build_id()) if pm.get("build_id") else None
+    hb = None
     if "hbm_bytes_per_launch" in k:
         r["traffic"] = int(k["hbm_bytes_per_launch"])
-        r["hbm_true_GBps"] = round(r["traffic"] / dom_avg_s / 1e9, 1)
-        r["hbm_true_frac"] = round(r["traffic"] / dom_avg_s / 1e9 / HBM_PEAK_GBS, 4)
+        hb = min(1.0, r["traffic"] / dom_avg_s / 1e9 / HBM_PEAK_GBS)
+        r["frac_hbm_unique"] = round(hb, 4)
         r["traffic_over_algorithmic"] = round(r["traffic"] / dom_bytes, 3)
     if "l2_hit_rate" in k:
         r["l2_hit_rate"] = k["l2_hit_rate"]
     v = k.get("valu")
+    busy = None
     if v:
         # tools/pmc_summary.py: busy quad-cycles = SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2 (the SIMD pairs plain fp32 ops),
         # cycles = SQ_BUSY_CYCLES / 32 of the SAME pass, normalised by what a saturated probe of the kernel's own
@@ -179,25 +208,35 @@ def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix
         valu = {kk: v[kk] for kk in ("valu_busy", "valu_busy_raw", "calibration_probe", "probe_reads_raw", "dual_issued_frac", "valu_insts",
                                      "cycles", "clock_GHz", "pass_dur_us", "wave_cycles_split", "lds_inst_busy")
                 if kk in v}
+        busy = min(1.0, valu.get("valu_busy", valu.get("valu_busy_raw", 0.0)))
+        valu["busy"] = busy
+        valu["issued_insts_per_launch"] = v["valu_insts"]
         if mix_chunks and dom.startswith("k_mix"):
-            valu["insts_per_1024_sample_chunk"] = round(v["valu_insts"] / mix_chunks, 1)
+            valu["issued_insts_per_chunk"] = round(v["valu_insts"] / mix_chunks, 1)
+        if demanded and dom.startswith("k_mix"):
+            # the part of the launch's VALU capacity spent on instructions the reference's arithmetic demands
+            valu["demanded_insts_per_launch"] = int(demanded)
+            if mix_chunks:
+                valu["demanded_insts_per_chunk"] = round(demanded / mix_chunks, 1)
+            valu["useful_frac"] = round(min(busy, 4.0 * demanded / (1024 * v["cycles"]) / valu.get("probe_reads_raw", 1.0)), 4)
         if "inst_mix" in pm and dom.startswith("k_mix"):
             valu["inst_mix_per_chunk"] = pm["inst_mix"]
         r["valu"] = valu
-        busy = valu.get("valu_busy", valu.get("valu_busy_raw", 0.0))
-        r["valu_busy"] = busy  # the fraction of what really binds the launch (calibrated; details in `valu`)
-        hb = r.get("hbm_true_frac", 0.0)
-        r["limiter"] = "valu" if busy > hb else "hbm"
-        r["limited_by"] = (f"VALU issue: {busy:.0%} of the launch's cycles carry a VALU instruction (calibrated) -- not HBM: real traffic "
-                           f"is {hb:.0%} of the 8 TB/s peak, siblings share the parent's stream through L2"
-                           if busy > hb else f"HBM ({hb:.0%} of peak in real traffic)")
-    if r["frac"] > 1.0:
-        # SURVEY 8d's algorithmic bytes count 8*n_in for EVERY sibling although they share one parent stream through L2:
-        # above 1 the figure is no fraction of anything -- the contract figure stays in `achieved`, the bound is `limiter`
-        r["algorithmic_over_peak"] = r["frac"]
-        r["frac"] = None
-        r["frac_note"] = ("algorithmic bytes / launch time exceeds the 8 TB/s peak: siblings share the parent's stream through L2, so HBM "
-                          "does not bound this launch (see traffic, hbm_true_frac and valu)")
+    if busy is not None and (hb is None or busy > hb):
+        slots = v["valu_insts"] * (1.0 - v.get("dual_issued_frac", 0.0) / 2.0)  # issue slots carrying an instruction
+        r["bound"], r["unit"] = "valu", "G VALU issue slots/s"
+        r["achieved"] = round(slots / (v["pass_dur_us"] * 1e3), 1)
+        r["peak"] = round(r["achieved"] / busy, 1) if busy > 0 else None  # = 1024 SIMDs x clock / 4 x what a saturated probe reads
+        r["frac"] = round(busy, 4)
+        r["limited_by"] = (f"VALU issue: {busy:.0%} of the launch's issue slots carry a VALU instruction (calibrated) -- not HBM: "
+                           + (f"real traffic is {hb:.0%} of the 8 TB/s peak, siblings share the parent's stream through L2" if hb is not None
+                              else "no traffic counters"))
+    elif hb is not None:
+        r["bound"], r["unit"], r["peak"] = "hbm", "GB/s", HBM_PEAK_GBS
+        r["achieved"] = round(r["traffic"] / dom_avg_s / 1e9, 1)
+        r["frac"] = round(hb, 4)
+        r["limited_by"] = f"HBM: {hb:.0%} of the 8 TB/s peak in real traffic (counter bytes)" + (f"; VALU issue {busy:.0%}" if busy is not None else "")
+    r["limiter"] = r["bound"]
     return r
 
 
@@ -400,12 +439,25 @@ def main():
                  "frame_frac": round(args.steps * j.st["algorithmic_bytes_per_frame"] / sdt / 1e9 / HBM_PEAK_GBS, 4)}
             if sdom:
                 o["roofline"] = roofline_object(sdom, skt[sdom], ks, sfk, j.st["algorithmic_bytes_per_frame"], 1,
-                                                pmc_for(name, not args.fast), j.st["mix_chunks_per_frame"])
+                                                pmc_for(name, not args.fast), j.st["mix_chunks_per_frame"], demanded_valu_per_launch(j.topo))
             o["kernels"] = {k: v["avg_ms"] for k, v in skern.items()}
             j.close()
             return o
         except Exception as e:  # the bench line must still come out
             return {"error": f"{type(e).__name__}: {e}"}
+
+    diag_world, diag_peer = None, None
+    if use_dist:
+        # so that the first run on several devices diagnoses itself: what the process group says, who reaches whom
+        diag_world = dist.get_world_size()
+        try:
+            ok = 1 if (local == 0 or share) else int(torch.cuda.can_device_access_peer(local, 0))
+        except Exception:
+            ok = -1
+        t = torch.zeros(world, dtype=torch.int64, device="cuda")
+        t[rank] = ok
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        diag_peer = [int(x) for x in t.tolist()]
 
     job = Job(workload)
     topo, rx, st, full, descr = job.topo, job.rx, job.st, job.full, job.descr
@@ -501,7 +553,7 @@ def main():
     if abi is not None and workload == "config3" and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdropin_sdrx.so")):
         import subprocess
         qt = {}
-        for label, env in (("sync", {}), ("sync_one_upload_per_main", {"SDRX_SHARE_UPLOAD": "0"}), ("pipelined", {"SDRX_PIPELINE": "1"})):
+        for label, env in (("sync", {}), ("sync_shared_upload", {"SDRX_SHARE_UPLOAD": "1"}), ("pipelined", {"SDRX_PIPELINE": "1"})):
             try:
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dropin_run.py"), "time", "sdrx", "1024", "12"],
                                    capture_output=True, text=True, timeout=300, env=dict(os.environ, SDRX_DEVICE=str(local), **env))
@@ -559,7 +611,8 @@ def main():
         }
         if dom:
             pm = pmc_for(workload, not args.fast)
-            out["roofline"] = roofline_object(dom, kt[dom], kt_steps, frame_kernel_ms, alg_bytes, world, pm, st["mix_chunks_per_frame"])
+            out["roofline"] = roofline_object(dom, kt[dom], kt_steps, frame_kernel_ms, alg_bytes, world, pm, st["mix_chunks_per_frame"],
+                                              demanded_valu_per_launch(topo) if world == 1 else None)
         out["kernels"] = kernels
         if abi:
             out["through_abi"] = abi
@@ -567,6 +620,9 @@ def main():
             # what a C host sees (host/abi_bench.c) where it ran, else the same loops through ctypes
             out["ms_per_step_through_abi"] = ch.get("sdrx_submit_wait_ms", abi["pipelined_pageable_ms"])
             out["ms_per_step_with_payload_d2h"] = ch.get("sdrx_process_ms", abi["sync_pageable_ms"])
+        if use_dist:
+            out["rccl_world"] = diag_world  # the world size the collective library reports ...
+            out["peer_ok"] = diag_peer      # ... and per rank: can its device reach rank 0's directly (hipDeviceCanAccessPeer)?
         if weak:
             out["weak_config3"] = weak
         if side:

@@ -29,8 +29,10 @@
 // is called first uploads the frame; a root of another tree on the same device that is then called runs on that
 // uploaded copy (sdrx_process_if_same / sdrx_submit_if_same) if -- and only if -- its samples ARE the uploaded frame:
 // the library compares them byte for byte with the uploader's pinned staging copy (a memcmp of the frame instead of
-// its upload; no address or spot-check heuristics).  One PCIe crossing per frame instead of one per main VFO.
-// SDRX_SHARE_UPLOAD=0 switches it off.
+// its upload; no address or spot-check heuristics).  One PCIe crossing per frame instead of one per main VFO -- which,
+// measured on config 3 (two mains, bench.py through_abi.qt_adapter), buys nothing: 1.833 ms per frame with it, 1.830
+// without (the comparison costs the host what the upload's staging copy did; the copy engine was idle anyway).  So it
+// is OFF unless SDRX_SHARE_UPLOAD=1 asks for it.
 //
 // SDRX_PIPELINE=1: process() only SUBMITS its frame (sdrx_submit*) and delivers the PREVIOUS frame's payloads --
 // the frame's kernels and the payload copy of the one before run concurrently, 0.30 instead of 0.55 ms per frame
@@ -376,7 +378,7 @@ void vfo::process(const std::vector<cpx_typef> &samples)
     // hands every main VFO the same vector, sdrj.cpp:288-294, but `class vfo` cannot know that): the library compares the
     // caller's frame byte for byte with that tree's pinned staging copy (sdrx_*_if_same: a memcmp instead of an upload) and
     // runs this tree on the frame already on the device only if they are equal.
-    const bool may_share = T.ctx && n > 0 && !(std::getenv("SDRX_SHARE_UPLOAD") && std::atoi(std::getenv("SDRX_SHARE_UPLOAD")) == 0);
+    const bool may_share = T.ctx && n > 0 && std::getenv("SDRX_SHARE_UPLOAD") && std::atoi(std::getenv("SDRX_SHARE_UPLOAD")) != 0;
     Upload *U = may_share ? &uploads()[T.device] : nullptr;
     sdrx_ctx *from = (U && U->owner && U->owner != &T) ? U->owner->ctx : nullptr;
     bool shared = false;

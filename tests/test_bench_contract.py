@@ -18,22 +18,55 @@ def _bench():
     return m
 
 
-@pytest.mark.parametrize("name,ms,alg", [("current_pmc.json", 0.0766, 597120000), ("pmc_10k.json", 0.70, 5905536000)])
-def test_roofline_object_keeps_the_contract_keys(name, ms, alg):
+def _fracs(o, path=""):
+    """every (path, value) of a key named `frac` anywhere inside o"""
+    if isinstance(o, dict):
+        for k, v in o.items():
+            if k == "frac":
+                yield path + "/frac", v
+            yield from _fracs(v, path + "/" + k)
+    elif isinstance(o, list):
+        for i, v in enumerate(o):
+            yield from _fracs(v, f"{path}[{i}]")
+
+
+@pytest.mark.parametrize("name,dom,ms,alg,workload", [("current_pmc.json", "k_mix_levels", 0.0766, 597120000, "config3"),
+                                                      ("pmc_10k.json", "k_mix_levels", 0.70, 5905536000, "10k"),
+                                                      ("pmc_flat.json", "k_mix_decimate(level0)", 0.36, 3145728000, "flat"),
+                                                      ("pmc_config4.json", "k_mix_levels", 0.032, 135840000, "config4")])
+def test_roofline_object_keeps_the_contract_keys(name, dom, ms, alg, workload):
+    """`frac` is the fraction of the bound that binds (<= 1 by construction), `bound` is that limiter -- never a label that
+    disagrees with the counters -- and SURVEY 8d's algorithmic figure, which may exceed the peak, is not called a fraction."""
     b = _bench()
     pm = json.load(open(os.path.join(ROOT, "profiles", name)))
-    r = b.roofline_object("k_mix_levels", {"alg_bytes": alg * 20, "launches": 20, "ms": ms * 20}, 20, 2 * ms, alg, 1, pm, 70000)
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    if dom not in pm["kernels"]:
+        dom = next(k for k in pm["kernels"] if k.startswith("k_mix"))
+    from sdrreceiver_amd import topology as tp
+    topo = {"config3": lambda: tp.config3(1024), "10k": lambda: tp.config3(10240), "flat": lambda: tp.config3_flat(1024),
+            "config4": lambda: tp.config4(256)}[workload]()
+    r = b.roofline_object(dom, {"alg_bytes": alg * 20, "launches": 20, "ms": ms * 20}, 20, 2 * ms, alg, 1, pm, 70000,
+                          b.demanded_valu_per_launch(topo))
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_GBps", "frac_hbm_unique"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["achieved"] - alg / (ms * 1e-3) / 1e9) < 1.0
-    if r["achieved"] <= r["peak"]:
-        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    else:  # the contract figure exceeds the peak: no fraction, the reason instead
-        assert r["frac"] is None and r["algorithmic_over_peak"] > 1.0 and "frac_note" in r
+    assert r["bound"] in ("hbm", "valu") and r["bound"] == r["limiter"]
+    assert abs(r["algorithmic_GBps"] - alg / (ms * 1e-3) / 1e9) < 1.0
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
+    assert 0.0 < r["frac_hbm_unique"] <= 1.0
+    for path, v in _fracs(r):
+        assert v is None or 0.0 <= v <= 1.0, (path, v)
+    if r["bound"] == "hbm":
+        assert r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["frac"] == r["frac_hbm_unique"] >= r["valu"]["busy"]
+    else:
+        assert r["frac"] == r["valu"]["busy"] > r["frac_hbm_unique"]
     assert isinstance(r["traffic"], int) and r["traffic"] > 0
     v = r["valu"]
-    assert 0.0 < v["valu_busy"] <= 1.0 and v["calibration_probe"] == "mixlike" and r["limiter"] in ("valu", "hbm")
+    assert 0.0 < v["busy"] <= 1.0 and 0.0 < v["useful_frac"] <= v["busy"] and v["demanded_insts_per_launch"] <= v["issued_insts_per_launch"] * 1.5
+
+
+def test_roofline_object_without_counters_claims_nothing():
+    b = _bench()
+    r = b.roofline_object("k_mix_levels", {"alg_bytes": 6e9, "launches": 10, "ms": 0.7}, 10, 0.1, 6e8, 1, None, 1000)
+    assert r["bound"] is None and r["frac"] is None and r["algorithmic_GBps"] > 8000 and "unknown" in r["limited_by"]
 
 
 def test_no_committed_kernel_reads_more_than_fully_busy():
@@ -64,8 +97,11 @@ def test_default_bench_line_has_every_contract_field():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["scaling"] == "weak" and d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_GBps"):
         assert k in d["roofline"], k
+    assert d["roofline"]["bound"] == d["roofline"]["limiter"]
+    for path, v in _fracs(d):
+        assert v is None or 0.0 <= v <= 1.0, (path, v)
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] in ("reference", "port")

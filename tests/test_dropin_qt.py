@@ -112,13 +112,14 @@ def test_adapter_over_a_device_list():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"SDRX_PIPELINE": "1"}, {"SDRX_SHARE_UPLOAD": "0"}, {"SDRX_PIPELINE": "1", "SDRX_SHARE_UPLOAD": "0"},
+@pytest.mark.parametrize("env", [{"SDRX_PIPELINE": "1"}, {"SDRX_SHARE_UPLOAD": "1"}, {"SDRX_PIPELINE": "1", "SDRX_SHARE_UPLOAD": "1"},
                                  {"SDRX_PIPELINE": "1", "SDRX_DEVICES": "0,0"}])
 def test_adapter_modes_publish_the_same_bytes(env):
     """The adapter's host-side modes change WHEN bytes move, never which: SDRX_PIPELINE=1 (process() submits its
     frame and delivers the previous one -- sdrx_submit* / sdrx_wait -- the last frame at the tree's deletion),
-    with and without the shared upload (by default the second main VFO of a receiver runs on the frame the first
-    one uploaded: sdrx_process_shared / sdrx_submit_shared), and over a device list.  profile_25e has two main
+    with and without the shared upload (SDRX_SHARE_UPLOAD=1: the second main VFO of a receiver runs on the frame the first
+    one uploaded once the library has compared the two byte for byte: sdrx_process_if_same / sdrx_submit_if_same), and over
+    a device list.  profile_25e has two main
     VFOs and an fftData tap on one sub VFO: the subscriber's stream and the fftData log stay the reference's."""
     got, want = _run("sdrx", "profile_25e", env=env)
     assert len(got) == len(want)
@@ -141,7 +142,7 @@ def _raw(kind, name, frames, fft, env):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [{}, {"SDRX_PIPELINE": "1"}])
+@pytest.mark.parametrize("mode", [{"SDRX_SHARE_UPLOAD": "1"}, {"SDRX_SHARE_UPLOAD": "1", "SDRX_PIPELINE": "1"}, {}])
 @pytest.mark.parametrize("mutate", ["1", "2", "3"])
 def test_adapter_processes_what_it_is_handed(mutate, mode):
     """sdrj::demodData reuses one `samples` vector for every frame and every main VFO, so the address and the length of
