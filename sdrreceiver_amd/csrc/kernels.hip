@@ -19,6 +19,9 @@
 // frame chunk by chunk with the filter state resident in LDS.
 #include "sdrx_dev.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace sdrx {
 
 // Pointers that come out of a descriptor in memory are generic ("flat") to the compiler.  They
@@ -83,31 +86,67 @@ __device__ __forceinline__ v2f cmul(v2f a, v2f b)
     const v2f pm = {-1.0f, 1.0f};
     return __builtin_elementwise_fma(t2, pm, t1);
 }
-// (h, h) * w and fma((h, h), w, c) with h = the low (HI = 0) or high (HI = 1) half of a PAIR of taps: op_sel / op_sel_hi pick
-// that half for both lanes of the packed instruction.  (Written as `v2f{h, h} * w` the compiler materialises the pair
-// (h, h) with two v_mov per tap, and the registers to hold them.)  Each lane is an ordinary IEEE fp32 operation.
-// `after`: a value the product is to be computed AFTER (an operand the instruction does not read).  The products of a FIR
-// do not depend on its accumulators, so a scheduler is free to compute all of them first -- and spill them; tied to the
-// accumulator they are added to, at most one product per chain is in flight.
-template <int HI>
-__device__ __forceinline__ v2f pk_mul_bcast(v2f hpair, v2f w, v2f after)
+// One window sample w of a FIR feeding up to three accumulator chains: a_r += (h_r, h_r) * w with h_r = the low (H_r = 0) or
+// high (H_r = 1) half of a PAIR of taps -- op_sel / op_sel_hi pick that half for both lanes of the packed instruction.
+// (Written as `v2f{h, h} * w` the compiler materialises every pair (h, h) with two v_mov and the registers to hold them.)
+// EXACT: product and sum rounded separately, the products first and the sums behind them so that no instruction waits for the
+// one before it; all of it in ONE asm statement: a scheduler cannot pull the products of later samples up front (they do
+// not depend on the accumulators: it did, and spilled them), and the hazard recogniser, which puts a wait state behind every
+// asm statement whose result the next instruction reads, sees one statement per sample instead of one per product.
+// Each lane of each instruction is an ordinary IEEE fp32 operation.
+template <bool EXACT, int H0>
+__device__ __forceinline__ void fir_mac1(v2f &a0, v2f h0, v2f w)
 {
-    v2f r;
-    if (HI)
-        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(hpair), "v"(w), "v"(after));
+    v2f t0;
+    if (EXACT)
+        // (gfx950 wants one wait state between a packed fp32 instruction and a reader of its result -- the compiler puts an
+        // s_nop there in its own code; inside an asm statement nobody does.  With two or three chains the other products are
+        // that wait state.)
+        asm("v_pk_mul_f32 %1, %2, %3 op_sel:[%4,0] op_sel_hi:[%4,1]\n\ts_nop 0\n\tv_pk_add_f32 %0, %0, %1" : "+v"(a0), "=&v"(t0) : "v"(h0), "v"(w), "n"(H0));
     else
-        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(hpair), "v"(w), "v"(after));
-    return r;
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[%3,0,0] op_sel_hi:[%3,1,1]" : "+v"(a0) : "v"(h0), "v"(w), "n"(H0));
 }
-template <int HI>
-__device__ __forceinline__ v2f pk_fma_bcast(v2f hpair, v2f w, v2f c)
+template <bool EXACT, int H0, int H1>
+__device__ __forceinline__ void fir_mac2(v2f &a0, v2f &a1, v2f h0, v2f h1, v2f w)
 {
-    v2f r;
-    if (HI)
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(hpair), "v"(w), "v"(c));
+    v2f t0, t1;
+    if (EXACT)
+        asm("v_pk_mul_f32 %2, %4, %6 op_sel:[%7,0] op_sel_hi:[%7,1]\n\tv_pk_mul_f32 %3, %5, %6 op_sel:[%8,0] op_sel_hi:[%8,1]\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3"
+            : "+v"(a0), "+v"(a1), "=&v"(t0), "=&v"(t1)
+            : "v"(h0), "v"(h1), "v"(w), "n"(H0), "n"(H1));
     else
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(hpair), "v"(w), "v"(c));
-    return r;
+        asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel:[%5,0,0] op_sel_hi:[%5,1,1]\n\tv_pk_fma_f32 %1, %3, %4, %1 op_sel:[%6,0,0] op_sel_hi:[%6,1,1]"
+            : "+v"(a0), "+v"(a1)
+            : "v"(h0), "v"(h1), "v"(w), "n"(H0), "n"(H1));
+}
+template <bool EXACT, int H0, int H1, int H2>
+__device__ __forceinline__ void fir_mac3(v2f &a0, v2f &a1, v2f &a2, v2f h0, v2f h1, v2f h2, v2f w)
+{
+    v2f t0, t1, t2;
+    if (EXACT)
+        asm("v_pk_mul_f32 %3, %6, %9 op_sel:[%10,0] op_sel_hi:[%10,1]\n\tv_pk_mul_f32 %4, %7, %9 op_sel:[%11,0] op_sel_hi:[%11,1]\n\t"
+            "v_pk_mul_f32 %5, %8, %9 op_sel:[%12,0] op_sel_hi:[%12,1]\n\t"
+            "v_pk_add_f32 %0, %0, %3\n\tv_pk_add_f32 %1, %1, %4\n\tv_pk_add_f32 %2, %2, %5"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "=&v"(t0), "=&v"(t1), "=&v"(t2)
+            : "v"(h0), "v"(h1), "v"(h2), "v"(w), "n"(H0), "n"(H1), "n"(H2));
+    else
+        asm("v_pk_fma_f32 %0, %3, %6, %0 op_sel:[%7,0,0] op_sel_hi:[%7,1,1]\n\tv_pk_fma_f32 %1, %4, %6, %1 op_sel:[%8,0,0] op_sel_hi:[%8,1,1]\n\t"
+            "v_pk_fma_f32 %2, %5, %6, %2 op_sel:[%9,0,0] op_sel_hi:[%9,1,1]"
+            : "+v"(a0), "+v"(a1), "+v"(a2)
+            : "v"(h0), "v"(h1), "v"(h2), "v"(w), "n"(H0), "n"(H1), "n"(H2));
+}
+// f(std::integral_constant<int, 0>{}), ..., f(integral_constant<int, N - 1>{}): a loop whose index is a constant EXPRESSION
+// inside the body (the op_sel digits above are template arguments)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 __device__ __forceinline__ v2f gldv2(const float2 *p) { return *(const SDRX_AS1 v2f *)p; }
 __device__ __forceinline__ v4f gldv4(const float4 *p) { return *(const SDRX_AS1 v4f *)p; }
@@ -1265,7 +1304,8 @@ __device__ __forceinline__ void late_item(const K1Vfo *__restrict__ vfos, const 
         }
         // 3. to LDS, rows of 3 L samples
         wave_sync(); // the previous chunk's window reads and its carry rows are done
-        asm volatile("" : "+v"(wr_T)); // (16 selects per chunk instead of 16 addresses kept -- and spilled -- across the loop)
+        if (LD == 6) // (/6: 16 selects per chunk instead of 16 addresses kept across the loop -- there they spill; /5 keeps them)
+            asm volatile("" : "+v"(wr_T));
         if (lane < G::kMixLanes) {
 #pragma unroll
             for (int i = 0; i < kRun; ++i)
@@ -1278,11 +1318,11 @@ __device__ __forceinline__ void late_item(const K1Vfo *__restrict__ vfos, const 
         //    stride keeps pairs 16-byte aligned; single b64 reads otherwise.
         if (lane < G::kRows) {
             v2f acc[3] = {zero2, zero2, zero2};
-#pragma unroll
-            for (int fl = -G::kCarryRows; fl <= 0; ++fl) {
-                const int u_lo = kRow * fl < -N ? -N : kRow * fl, u_hi = kRow * (fl + 1) > 2 * LD ? 2 * LD : kRow * (fl + 1);
+            static_for<G::kCarryRows + 1>([&](auto row_ic) {
+                constexpr int fl = decltype(row_ic)::value - G::kCarryRows; // window row, -kCarryRows .. 0
+                constexpr int u_lo = kRow * fl < -N ? -N : kRow * fl, u_hi = kRow * (fl + 1) > 2 * LD ? 2 * LD : kRow * (fl + 1);
                 // taps this row touches: t = u - L r + N for u in [u_lo, u_hi), r in 0..2
-                const int t_lo = (u_lo + N - 2 * LD < 0 ? 0 : u_lo + N - 2 * LD) & ~3;
+                constexpr int t_lo = (u_lo + N - 2 * LD < 0 ? 0 : u_lo + N - 2 * LD) & ~3;
                 constexpr int kHv = (kRow + 2 * LD + 8) / 2;
                 v2f hv[kHv]; // tap PAIRS (t_lo + 2 q, + 1): a packed multiply takes either half for both of its lanes
 #pragma unroll
@@ -1306,25 +1346,28 @@ __device__ __forceinline__ void late_item(const K1Vfo *__restrict__ vfos, const 
                         w[col] = row[col];
                     }
                 }
-#pragma unroll
-                for (int col = 0; col < kRow; ++col) {
-                    const int u = kRow * fl + col;
-                    if (u < u_lo || u >= u_hi)
-                        continue;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const int t = u - LD * r + N;
-                        if (t >= 0 && t < N) {
-                            const v2f hp = hv[(t - t_lo) >> 1];
-                            if ((t - t_lo) & 1)
-                                acc[r] = EXACT ? acc[r] + pk_mul_bcast<1>(hp, w[col], acc[r]) : pk_fma_bcast<1>(hp, w[col], acc[r]);
-                            else
-                                acc[r] = EXACT ? acc[r] + pk_mul_bcast<0>(hp, w[col], acc[r]) : pk_fma_bcast<0>(hp, w[col], acc[r]);
-                        }
+                static_for<kRow>([&](auto col_ic) {
+                    constexpr int col = decltype(col_ic)::value, u = kRow * fl + col;
+                    if constexpr (u >= u_lo && u < u_hi) {
+                        // output r takes tap t_r = u - L r + N of this sample if 0 <= t_r < N: r in [r_lo, r_hi]
+                        constexpr int i0 = u + N - t_lo, i1 = i0 - LD, i2 = i0 - 2 * LD; // tap index - t_lo per output
+                        constexpr bool on0 = u + N >= 0 && u + N < N, on1 = u - LD + N >= 0 && u - LD + N < N, on2 = u - 2 * LD + N >= 0 && u - 2 * LD + N < N;
+                        if constexpr (on0 && on1 && on2)
+                            fir_mac3<EXACT, i0 & 1, i1 & 1, i2 & 1>(acc[0], acc[1], acc[2], hv[i0 >> 1], hv[i1 >> 1], hv[i2 >> 1], w[col]);
+                        else if constexpr (on0 && on1)
+                            fir_mac2<EXACT, i0 & 1, i1 & 1>(acc[0], acc[1], hv[i0 >> 1], hv[i1 >> 1], w[col]);
+                        else if constexpr (on1 && on2)
+                            fir_mac2<EXACT, i1 & 1, i2 & 1>(acc[1], acc[2], hv[i1 >> 1], hv[i2 >> 1], w[col]);
+                        else if constexpr (on0)
+                            fir_mac1<EXACT, i0 & 1>(acc[0], hv[i0 >> 1], w[col]);
+                        else if constexpr (on2)
+                            fir_mac1<EXACT, i2 & 1>(acc[2], hv[i2 >> 1], w[col]);
+                        else
+                            static_assert(!on1, "a window sample feeds a contiguous range of outputs");
                     }
-                }
+                });
                 __builtin_amdgcn_sched_barrier(0); // a row's reads stay in the row (all hoisted to the top they spill)
-            }
+            });
             const int pos = base + kRow * lane; // input position L k of the lane's first output
 #pragma unroll
             for (int r = 0; r < 3; ++r)
