@@ -83,7 +83,9 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
 /* Options, all before sdrx_finalize:
  *   "exact"  1 (default): every fp32 operation rounded like the reference's -O2 x86-64 build
  *            (no FMA contraction, reference summation order) -> results bit-identical to it.
- *            0: FMA and tree-order dot products; within 1e-6 relative of the reference.
+ *            0: an A/B SWITCH, not a feature: the filters' multiply-adds as FMAs (within 1e-6 relative of the
+ *            reference, int16 within 1 LSB).  It buys ~5 % on this hardware -- a packed or paired mul + add issues
+ *            as fast as an FMA here (profiles/README.md) -- and is kept so that the cost of exactness stays measurable.
  *   "keep_prequant" 1: also keep the pre-quantisation float `usb*gain*32768` per leaf
  *            (parity tests; sdrx_get_prequant).   default 0
  *   "segments" n: force n time-segments per VFO-frame in the decimation kernel (0 = auto).

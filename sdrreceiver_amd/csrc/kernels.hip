@@ -574,7 +574,7 @@ __device__ __forceinline__ v2f shr1(v2f old, v2f src)
 // and (only when a d == 0 VFO must emit natural order) a padded transpose tile.
 constexpr int kRegStages = 2;                       // stages 0 and 1 live in registers
 constexpr int kCarryBytes = 2 * 8 * 8;              // car0[8], car1[8] float2
-__host__ __device__ constexpr int stage_elems(int s) { return kCarry + (kChunk >> s); }
+__host__ __device__ constexpr int stage_elems(int s) { return kCarry + (s >= 3 ? 2 : 1) * (kChunk >> s); } // (stages >= 3: two chunks' worth, hb_stage_fixed)
 __host__ __device__ constexpr int stage_offset(int s) // float2 index of A_s, s >= kRegStages
 {
     int o = 0;
@@ -712,12 +712,19 @@ __device__ __forceinline__ void hb_stage_lds(v2f *__restrict__ A, v2f *__restric
 #define SDRX_FIXED_STAGES 1
 #endif
 constexpr int kFixedDepth = 5; // 1.536 MS/s / 384 kS/s -> 48 / 12 kS/s: the depth of the reference's sub VFOs below a 384 k main
-template <bool EXACT, int S, int D>
-__device__ __forceinline__ void hb_stage_fixed(v2f *__restrict__ lds, float2 *__restrict__ gout, int gbase, int jmin, int lane)
+// Stage S of a full chunk: A_S = [16 carry | M * (1024 >> S) inputs] -> outputs into B's data from entry `boff` on, or -- the last stage --
+// to the leaf's stream.  M = 2: the stage runs every SECOND chunk on two chunks' worth of input (SDRX_PAIR_STAGES: stages >= 3
+// of a d = 5 leaf, whose last stage otherwise fills 32 of the 64 lanes; one carry hand-over and one set of phase fences per
+// two chunks).  Same arithmetic on the same values in the same order: an output does not know how many of its neighbours
+// were computed in the same pass.
+template <bool EXACT, int S, int D, int M, int boff = 0>
+__device__ __forceinline__ void hb_stage_fixed1(v2f *__restrict__ lds, float2 *__restrict__ gout, int gbase, int jmin, int lane)
 {
-    constexpr int cnt = kChunk >> S, nout = cnt >> 1;
+    constexpr int cnt = M * (kChunk >> S), nout = cnt >> 1;
     v2f *A = lds + stage_offset(S);
     v2f *B = lds + stage_offset(S + 1); // (not touched by the last stage)
+    if constexpr (M == 2) // (the pass's LDS addresses are computed here, from this: hoisted out of the chunk loop one of them spills)
+        asm volatile("" : "+v"(lane));
     wave_sync(); // stage input (written by the previous phase) is visible
     if constexpr (nout >= 64) {
 #pragma unroll
@@ -726,7 +733,7 @@ __device__ __forceinline__ void hb_stage_fixed(v2f *__restrict__ lds, float2 *__
             const v2f *w = A + kCarry + 2 * j - 10;
             const v2f y = hb_dot2<EXACT>(w[0], w[2], w[4], w[5], w[6], w[8], w[10]);
             if constexpr (S + 1 < D)
-                B[kCarry + j] = y;
+                B[kCarry + boff + j] = y;
             else if (j >= jmin)
                 gstv2_leaf(gout + (size_t)(gbase + j), y);
         }
@@ -735,7 +742,7 @@ __device__ __forceinline__ void hb_stage_fixed(v2f *__restrict__ lds, float2 *__
             const v2f *w = A + kCarry + 2 * lane - 10;
             const v2f y = hb_dot2<EXACT>(w[0], w[2], w[4], w[5], w[6], w[8], w[10]);
             if constexpr (S + 1 < D)
-                B[kCarry + lane] = y;
+                B[kCarry + boff + lane] = y;
             else if (lane >= jmin)
                 gstv2_leaf(gout + (size_t)(gbase + lane), y);
         }
@@ -747,9 +754,18 @@ __device__ __forceinline__ void hb_stage_fixed(v2f *__restrict__ lds, float2 *__
     wave_sync();
     if (lane < kCarry)
         A[lane] = t;
-    if constexpr (S + 1 < D)
-        hb_stage_fixed<EXACT, S + 1, D>(lds, gout, gbase, jmin, lane);
 }
+// stages S .. D-1, each on M chunks' worth of input
+template <bool EXACT, int S, int D, int M>
+__device__ __forceinline__ void hb_stage_fixed(v2f *__restrict__ lds, float2 *__restrict__ gout, int gbase, int jmin, int lane)
+{
+    hb_stage_fixed1<EXACT, S, D, M>(lds, gout, gbase, jmin, lane);
+    if constexpr (S + 1 < D)
+        hb_stage_fixed<EXACT, S + 1, D, M>(lds, gout, gbase, jmin, lane);
+}
+#ifndef SDRX_PAIR_STAGES
+#define SDRX_PAIR_STAGES 1
+#endif
 
 // NOUT outputs of a register-resident stage.  ext[k] holds input sample k-10 of this lane's run
 // (k = 0..9: the halo, only the needed ones set).
@@ -846,6 +862,7 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         glds_wait();
     }
 #endif
+    int pair_base = -1; // >= 0: the stage-2 outputs of the chunk at this position wait in A_3 for the next chunk's (SDRX_PAIR_STAGES)
     for (int base = W.s_begin; base < W.s_end; base += kChunk) {
         const int valid = min(kChunk, D.n_in - base);
         const int p16 = (base >> 4) + lane;               // this lane's run, in units of 16 samples
@@ -1198,9 +1215,24 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
 #endif
 #if SDRX_FIXED_STAGES && !SDRX_GLDS
         if (valid == kChunk && !save && !D.out_tiled && D.d == kFixedDepth) { // (uniform) a full chunk of a leaf, not the frame's last
-            // outputs below jmin belong to the warm-up of a segment that starts inside the frame
+#if SDRX_PAIR_STAGES
+            // stage 2 every chunk; stages 3 and 4 every second chunk on both chunks' stage-2 outputs -- when the NEXT chunk
+            // of this item is such a chunk too (otherwise this one is finished alone: nothing pending ever meets another path)
+            if (pair_base < 0 && base + kChunk < W.s_end && base + 2 * kChunk < D.n_in) {
+                hb_stage_fixed1<EXACT, 2, kFixedDepth, 1>(lds, out, 0, 0, lane);
+                pair_base = base;
+                continue;
+            }
+            if (pair_base >= 0) {
+                hb_stage_fixed1<EXACT, 2, kFixedDepth, 1, (kChunk >> 3)>(lds, out, 0, 0, lane);
+                // outputs below jmin belong to the warm-up of a segment that starts inside the frame
+                hb_stage_fixed<EXACT, 3, kFixedDepth, 2>(lds, out, pair_base >> D.d, max(0, (first_out - pair_base) >> D.d), lane);
+                pair_base = -1;
+                continue;
+            }
+#endif
             const int jmin = max(0, (first_out - base) >> D.d), gbase = base >> D.d;
-            hb_stage_fixed<EXACT, 2, kFixedDepth>(lds, out, gbase, jmin, lane);
+            hb_stage_fixed<EXACT, 2, kFixedDepth, 1>(lds, out, gbase, jmin, lane);
             continue;
         }
 #endif
