@@ -12,6 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 NKERNELS = 8
 SDRX_EINVAL, SDRX_ESTATE, SDRX_EFILTER, SDRX_EHIP, SDRX_EUNSUPPORTED = -1, -2, -3, -4, -5  # include/sdrx.h
+SDRX_DIFFERENT = 1  # sdrx_*_if_same: the frame is not the one the source context staged
 
 
 class VfoDescC(C.Structure):

@@ -139,6 +139,25 @@ class Receiver:
     def submit_shared(self, src: "Receiver") -> None:
         self._chk(self.L.sdrx_submit_shared(self.h, src.h))
 
+    def process_if_same(self, src: "Receiver", iq) -> bool:
+        """Like process_shared, but only if `iq` IS the frame `src` staged last (the library compares it byte for byte with
+        src's pinned staging copy).  False -- and nothing processed -- when it is not."""
+        iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
+        self.published.clear()
+        rc = self.L.sdrx_process_if_same(self.h, src.h, iq.ctypes.data, iq.size // 2)
+        if rc == _lib.SDRX_DIFFERENT:
+            return False
+        self._chk(rc)
+        return True
+
+    def submit_if_same(self, src: "Receiver", iq) -> bool:
+        iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
+        rc = self.L.sdrx_submit_if_same(self.h, src.h, iq.ctypes.data, iq.size // 2)
+        if rc == _lib.SDRX_DIFFERENT:
+            return False
+        self._chk(rc)
+        return True
+
     def wait(self) -> None:
         """Blocks until the oldest undelivered frame's payloads are on the host; `published` then
         holds that frame's messages and output() serves it."""

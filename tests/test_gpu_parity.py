@@ -1371,3 +1371,48 @@ def test_two_contexts_share_one_uploaded_frame(Receiver):
     check(b, k1, 6)
     a.close()
     b.close()
+
+
+def test_a_frame_is_shared_only_if_it_is_the_same_frame(Receiver):
+    """sdrx_process_if_same / sdrx_submit_if_same: the second context runs on the first one's upload only when the frame
+    it is handed equals that upload byte for byte (the library compares it with the uploader's pinned staging copy);
+    one changed float anywhere -- here the last one, and one in the middle -- and the call answers SDRX_DIFFERENT without
+    queueing anything, the caller uploads, and either way the results are the oracle's for the frame that was HANDED."""
+    full = tp.profile_25e()
+    parts = []
+    for r in full.roots():
+        keep = [r] + full.children(r)
+        remap = {g: k for k, g in enumerate(keep)}
+        vf = [tp.VfoDesc(**{**full.vfos[g].__dict__, "parent": remap.get(full.vfos[g].parent, -1)}) for g in keep]
+        parts.append((keep, Receiver.from_topology(tp.Topology(fs=full.fs, frame=full.frame, vfos=vf))))
+    (k0, a), (k1, b) = parts
+    # the oracle runs the two mains on DIFFERENT inputs where the test hands them different frames
+    nodes, roots = ob.build_tree("port", full)
+    frames = [iq for _, iq in _frames(full, 6, seed=37, tones=[(200000.0, 18.0)])]
+    shared = []
+    for f, iq in enumerate(frames):
+        mine = iq.copy()
+        if f % 3 == 1:
+            mine[-1] += 1.0            # the very last float
+        elif f % 3 == 2:
+            mine[len(mine) // 2 + 1] -= 2.0
+        a.process(iq)
+        if f < 3:
+            ok = b.process_if_same(a, mine)
+            if not ok:
+                b.process(mine)
+        else:  # pipelined
+            ok = b.submit_if_same(a, mine)
+            if not ok:
+                b.submit(mine)
+            b.wait()
+        shared.append(ok)
+        ob.process_roots([roots[0]], iq)
+        ob.process_roots([roots[1]], mine)
+        for rx, keep in ((a, k0), (b, k1)):
+            for local, g in enumerate(keep):
+                if full.vfos[g].parent >= 0:
+                    assert np.array_equal(rx.output(local), nodes[g].usb()), (f, full.vfos[g].topic)
+    assert shared == [True, False, False, True, False, False]
+    a.close()
+    b.close()
