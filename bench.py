@@ -160,9 +160,9 @@ def demanded_valu_per_launch(topo):
         if d >= 2:
             per += 4 * 11 + 16
         for s_ in range(2, d):
-            per += 11 * max(1, (1024 >> (s_ + 1)) // 64)
+            per += 11 * (1024 >> (s_ + 1)) / 64.0  # (a stage with fewer than 64 outputs per chunk: a fraction of a wave-instruction)
         total += -(-n // 1024) * per
-    return total
+    return int(total)
 
 
 def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix_chunks, demanded=None):

@@ -51,8 +51,8 @@ INST_MIX_D5 = {
     "stage0_registers": 8 * 11,  # 3 pair sums, 4 products, 3 sums, 0+s -- per output (hb_dot2)
     "stage1_registers": 4 * 11,
     "dpp_halo_moves": 2 * 16,  # v_mov_b32_dpp wave_shr:1, two per shifted complex value, 8 values per stage
-    "stages2to4_lds": (2 + 1 + 1) * 11,  # 128 / 64 / 32 outputs per chunk over 64 lanes
-    "addressing_loop_stores": 46,        # the rest of the measured ~414: address arithmetic, selects, loop
+    "stages2to4_lds": (2 + 1 + 0.5) * 11,  # 128 / 64 / 32 outputs per chunk over 64 lanes (the last one every second chunk on 64)
+    "addressing_loop_stores": 26,          # the rest of the measured ~390: address arithmetic, selects, loop
 }
 
 
@@ -158,7 +158,7 @@ def main():
     res = {"source": os.path.relpath(d), "git_sha": sha, "build_id": build_id, "workload": workload, "exact": exact, "kernels": {},
            "inst_mix": {"k_mix_decimate, d=5 sub VFO, per 1024-sample chunk (source count, packed = 1)": INST_MIX_D5,
                         "sum": sum(INST_MIX_D5.values()),
-                        "isa_check": "tools/inst_mix.py: the static v_pk_mul/add/fma_f32 and DPP counts of kernels.s == the source count (148/91/32/32 executed per chunk; +16/+28 static for the unrolled fixed-depth LDS stages)"},
+                        "isa_check": "tools/inst_mix.py: the static v_pk_mul/add/fma_f32 and DPP counts of kernels.s == the source count (d = 5 leaf: 146/87.5/32/32 executed per chunk)"},
            "note": "per-launch medians; hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE correction); every derived "
                    "figure takes numerator, cycles and duration from ONE pass (tools/pmc_summary.py)"}
     kernels = sorted({k for p in passes for k in p})
