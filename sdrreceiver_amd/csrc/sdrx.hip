@@ -997,9 +997,12 @@ int build_mix_work(sdrx_ctx *c, Built &B)
         const int nchunks = (n_in + chunk - 1) / chunk;
         const int wch = (warm + chunk - 1) / chunk; // chunks a segment spends before its first exact output
         // few VFOs in the level (the 2-3 mains): segments as short as the warm-up allows;
-        // otherwise at least 4 chunks of useful work per segment (2 where a chunk carries the low-pass as well)
+        // otherwise at least 4 chunks of useful work per segment
         const bool few = (long long)B.level_count[(size_t)n.level] * nchunks < (long long)ncu * 16;
-        const int min_seg = few ? std::max(1, wch) : n.fused_late ? 2 : std::max(4, 4 * wch);
+        // (a fused late decimation: measured on config 4, interleaved: 2 / 3 / 4 / 6 / 8 chunks per segment = 0.0481 / 0.0484 /
+        // 0.0471 / 0.0482 / 0.0509 ms per step; SDRX_LATE_MINSEG for A/B runs)
+        const int late_min_seg = getenv("SDRX_LATE_MINSEG") ? std::max(1, atoi(getenv("SDRX_LATE_MINSEG"))) : 4;
+        const int min_seg = few ? std::max(1, wch) : n.fused_late ? late_min_seg : std::max(4, 4 * wch);
         int nseg = c->opt_segments > 0 ? c->opt_segments : std::min(level_nseg[(size_t)n.level], std::max(1, nchunks / min_seg));
         nseg = std::max(1, std::min(nseg, nchunks / std::max(1, wch)));
         // Segment s > 0 starts `warm` samples before its first emitted output and ends on a chunk
