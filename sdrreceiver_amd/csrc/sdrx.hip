@@ -1186,6 +1186,14 @@ void build_level_plan(sdrx_ctx *c, Built &B)
     LevelPlan &P = c->fp;
     P = LevelPlan();
     P.usable = c->n_levels >= 2 && c->n_levels <= kMaxLevels; // (one level: nothing to share a launch with)
+    // Frame k passes level l in launch k + l and gets its leaf tail behind launch k + n_levels - 1; the streams are double
+    // buffered by frame parity.  A leaf at level l is written in launch k + l and overwritten by frame k + 2 in launch
+    // k + l + 2: its tail must have run by then, i.e. l >= n_levels - 2 -- true for every tree the reference builds (two
+    // levels).  A deeper tree with a shallower leaf runs one launch per level instead (found by the 600-seed soak run of
+    // test_frame_pipeline_on_random_trees: seed 213, a parent-less leaf beside a three-level tree).
+    for (const Node &n : c->nodes)
+        if (n.leaf && n.level < c->n_levels - 2)
+            P.usable = false;
     if (!P.usable)
         return;
     // deepest level first: in the steady state of the reference's two-level trees the long sub-VFO

@@ -873,21 +873,25 @@ def _random_topology(rng):
     return t
 
 
+N_SEEDS = int(__import__("os").environ.get("SDRX_TEST_SEEDS", "60"))  # (a one-off soak run: SDRX_TEST_SEEDS=600)
+
+
 def test_random_trees_against_the_oracle(Receiver):
     """60 seeded random trees (shapes, depths, rates, frame lengths, filters, late decimation,
     compress styles), 3 frames each with tones: every stream and payload bit-identical to the
     oracle.  A tree the library refuses at sdrx_finalize must fall under a documented restriction
-    (here: a node rate below 1024 Hz); at least 55 must run."""
+    (here: a node rate below 1024 Hz, or a frame whose last 1024-sample chunk holds fewer than 256 samples -- one seed in
+    600); at least 55 of 60 must run."""
     from sdrreceiver_amd.receiver import SdrxError
     ran = 0
-    for seed in range(60):
+    for seed in range(N_SEEDS):
         rng = np.random.default_rng(1000 + seed)
         topo = _random_topology(rng)
         try:
             rx = Receiver.from_topology(topo, exact=True, segments=seed % 5, fuse=seed % 3 != 0,  # segments 0 = the library's own choice
                                         keep_streams=seed % 2 == 0, fuse_late=seed % 7 != 0)
         except SdrxError as e:
-            assert "fs >= 1024" in str(e), (seed, str(e))
+            assert "fs >= 1024" in str(e) or "last chunk shorter than 256" in str(e), (seed, str(e))  # DESIGN.md section 8
             continue
         nodes, roots = ob.build_tree("port", topo)
         for f, iq in _frames(topo, 3, seed=seed, tones=[(topo.fs / 7.3, 20.0), (-topo.fs / 3.1, 9.0)]):
@@ -896,7 +900,7 @@ def test_random_trees_against_the_oracle(Receiver):
             _check_exact(rx, nodes, topo, ("random", seed, f))
         rx.close()
         ran += 1
-    assert ran >= 55, ran
+    assert ran >= N_SEEDS * 55 // 60, ran
 
 
 @pytest.mark.parametrize("mode", ["one-launch, pipelined", "one-launch per part", "separate kernels"])
@@ -909,13 +913,13 @@ def test_frame_pipeline_on_random_trees(Receiver, mode):
     import torch
     from sdrreceiver_amd.receiver import SdrxError
     ran = 0
-    for seed in range(60):
+    for seed in range(N_SEEDS):
         rng = np.random.default_rng(1000 + seed)
         topo = _random_topology(rng)
         try:
             rx = Receiver.from_topology(topo, exact=True, segments=seed % 3, **LAUNCH_MODES[mode])
         except SdrxError as e:
-            assert "fs >= 1024" in str(e), (seed, str(e))
+            assert "fs >= 1024" in str(e) or "last chunk shorter than 256" in str(e), (seed, str(e))
             continue
         nodes, roots = ob.build_tree("port", topo)
         frames = [iq for _, iq in _frames(topo, 6, seed=seed, tones=[(topo.fs / 7.3, 20.0)])]
@@ -933,7 +937,32 @@ def test_frame_pipeline_on_random_trees(Receiver, mode):
         _check_exact(rx, nodes, topo, ("pipeline", mode, seed))
         rx.close()
         ran += 1
-    assert ran >= 55, ran
+    assert ran >= N_SEEDS * 55 // 60, ran
+
+
+def test_shallow_leaf_beside_a_deep_tree_in_the_frame_pipeline(Receiver):
+    """Found by a 600-seed soak run (seed 213): in the one-launch frame pipeline frame k gets its leaf tail behind launch
+    k + n_levels - 1, and the streams are double buffered -- a parent-less leaf beside a THREE-level tree was overwritten by
+    frame k + 2 before its demodulation had run (its 166-sample history spans three 64-output frames here, so every later
+    frame was wrong).  Such a tree runs one launch per level now; the reference's two-level trees are not affected."""
+    import torch
+    rng = np.random.default_rng(1000 + 213)
+    topo = _random_topology(rng)
+    levels = {}
+    for i, v in enumerate(topo.vfos):
+        levels[i] = 0 if v.parent < 0 else levels[v.parent] + 1
+    assert max(levels.values()) == 2 and any(levels[i] == 0 and not topo.children(i) for i in levels)
+    rx = Receiver.from_topology(topo, exact=True)
+    nodes, roots = ob.build_tree("port", topo)
+    frames = [iq for _, iq in _frames(topo, 8, seed=213, tones=[(topo.fs / 7.3, 20.0)])]
+    dev = [torch.from_numpy(iq).cuda() for iq in frames]
+    torch.cuda.synchronize()
+    for f, d in enumerate(dev):
+        rx.process_device(d.data_ptr(), topo.frame)
+        ob.process_roots(roots, frames[f])
+    rx.fetch()
+    _check_exact(rx, nodes, topo, "shallow leaf")
+    rx.close()
 
 
 def test_long_run_wraps_the_nco_tables_many_times(Receiver):
