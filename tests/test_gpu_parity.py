@@ -800,6 +800,37 @@ def test_u8_ingest_and_dc_bias_on_device(Receiver, correct_dc):
     rx.close()
 
 
+def test_dc_bias_removal_on_frames_of_every_shape(Receiver):
+    """The exact DC-bias removal walks the frame in groups of 32 samples with its scalar prefetch two groups ahead and a
+    line prefetch 16 groups ahead of that: frames of 16 m samples, m odd and even, from 1 024 to ~70 000 (a last group of 16
+    samples; frames shorter than the prefetch distance), the accumulator carried over five frames: bit-exact against the
+    oracle's sequential restatement of sdrj.cpp:277-283."""
+    cases = [1024, 1040, 1280 + 16, 2048, 4096 + 16 * 17, 8704, 16384 - 16, 20480 + 16, 69632 + 16 * 21]
+    rng = np.random.default_rng(11)
+    cases += [16 * int(m) for m in rng.integers(64, 4000, max(6, N_SEEDS // 10))]
+    for n in cases:
+        if 0 < n % 1024 < 256:
+            n += 256
+        t = tp.Topology(fs=4 * n, frame=n, name=f"dc{n}")
+        t.vfos.append(tp.VfoDesc(topic="DC0", parent=-1, fs=4 * n, decimate_count=1, mixer_freq=float(n // 3), filter_bw=0,
+                                 gain=tp._g(0.05), cstyle=1, samples_per_buffer=n))
+        t.vfos.append(tp.VfoDesc(topic="IQ0", parent=-1, fs=4 * n, decimate_count=0, mixer_freq=-float(n // 5), demod_usb=False,
+                                 cstyle=0, samples_per_buffer=n))
+        rx = Receiver.from_topology(t, exact=True)
+        nodes, roots = ob.build_tree("port", t)
+        state = np.zeros(2, np.float32)
+        for f in range(5):
+            b = rng.integers(0, 256, 2 * n, dtype=np.uint8)
+            b[1::2] = np.clip(b[1::2].astype(int) // 4 + 60, 0, 255)
+            rx.process_u8(b, correct_dc=True)
+            iq = ob.u8_to_float(b)
+            ob.dc_correct(iq, state)
+            ob.process_roots(roots, iq)
+            assert np.array_equal(bits(rx.raw()), bits(iq.view(np.complex64))), (n, f, "raw frame after the DC-bias removal")
+            _check_exact(rx, nodes, t, ("dc", n, f))
+        rx.close()
+
+
 # ------------------------------------------------------------------------------ edge geometry
 def _edge_topology():
     """Every decimation depth 0..8 (vfo.h:63 allows 8 stages) as parent-less USB leaves on a short
@@ -938,6 +969,50 @@ def test_frame_pipeline_on_random_trees(Receiver, mode):
         rx.close()
         ran += 1
     assert ran >= N_SEEDS * 55 // 60, ran
+
+
+def test_fused_late_decimation_random_geometries(Receiver):
+    """The /5 and /6 walks on frames of 960 .. 11 520 samples that are NOT multiples of their 960 / 1008-sample chunks
+    (partial last chunks of every length that is a multiple of 16 L), below mains of depth 0-2, with and without the audio
+    low-pass, 0-5 forced segments, four frames (the 60 / 90-sample history crosses three frame boundaries, the NCO tables
+    wrap): payloads, and decimate[0] where it is kept, bit-identical to the oracle."""
+    n_cases = max(40, N_SEEDS * 40 // 60)
+    ran = 0
+    for case in range(n_cases):
+        rng = np.random.default_rng(7000 + case)
+        L = int(rng.choice([5, 6]))
+        n = 16 * L * int(rng.integers(12 if L == 5 else 11, 121))
+        if 0 < n % 1024 < 256:
+            n += 16 * L * 4  # (a frame's last 1024-sample chunk must hold >= 256 samples: DESIGN.md section 8)
+            if 0 < n % 1024 < 256:
+                continue
+        dp = int(rng.integers(0, 3))
+        root_n = n << dp
+        if 0 < root_n % 1024 < 256:
+            continue
+        fs_root = root_n * int(rng.choice([1, 2, 4]))
+        t = tp.Topology(fs=fs_root, frame=root_n, name=f"late{case}")
+        t.vfos.append(tp.VfoDesc(parent=-1, fs=fs_root, decimate_count=dp, mixer_freq=float(int(rng.integers(-fs_root // 2 + 1, fs_root // 2))),
+                                 demod_usb=False, cstyle=1, samples_per_buffer=root_n))
+        fs = fs_root >> dp
+        for k in range(int(rng.integers(1, 4))):
+            rate = fs // L
+            bw = int(rate / rng.uniform(2.3, 10.0)) if rng.random() < 0.5 else 0
+            t.vfos.append(tp.VfoDesc(topic=f"F{case % 100:02d}{k}", parent=0, fs=fs, decimate_count=0,
+                                     mixer_freq=float(int(rng.integers(-fs // 2 + 1, fs // 2))), late_decimate=L, filter_bw=bw,
+                                     gain=tp._g(float(rng.uniform(0.01, 0.08))), cstyle=1, samples_per_buffer=n))
+        keep = bool(case % 2)
+        rx = Receiver.from_topology(t, exact=True, segments=int(rng.choice([0, 1, 2, 3, 5])), keep_streams=keep)
+        nodes, roots = ob.build_tree("port", t)
+        for f, iq in _frames(t, 4, seed=case, tones=[(t.fs / 5.7, 15.0)]):
+            rx.process(iq)
+            ob.process_roots(roots, iq)
+            _check_exact(rx, nodes, t, ("late geometry", case, L, n, dp, f))
+            if not keep:
+                assert rx.stream(1, missing_ok=True) is None  # (the fused path it is: decimate[0] of the leaves is not kept)
+        rx.close()
+        ran += 1
+    assert ran >= n_cases * 3 // 4, ran
 
 
 def test_shallow_leaf_beside_a_deep_tree_in_the_frame_pipeline(Receiver):
