@@ -971,6 +971,98 @@ def test_frame_pipeline_on_random_trees(Receiver, mode):
     assert ran >= N_SEEDS * 55 // 60, ran
 
 
+def test_random_api_sequences_on_random_trees(Receiver):
+    """The per-frame entry points mixed at random on the random trees: sdrx_process, sdrx_process_u8, the pipelined pair
+    sdrx_submit / sdrx_wait (one or two frames in flight), sdrx_process_device queued 1-4 deep with one sdrx_fetch, an
+    sdrx_sync or a stream read-back in between, the spectrum tap moved around.  Whatever the order, every DELIVERED frame's
+    payloads (and the streams, where the call leaves them readable) are the oracle's for that frame: the state that
+    connects the calls -- frame parity of every ping-pong buffer, the frame pipeline's in-flight levels, the filter
+    histories -- is what this exercises."""
+    import torch
+    from sdrreceiver_amd.receiver import SdrxError
+    ran = 0
+    for seed in range(N_SEEDS):
+        rng = np.random.default_rng(5000 + seed)
+        topo = _random_topology(np.random.default_rng(1000 + seed))
+        try:
+            rx = Receiver.from_topology(topo, exact=True, segments=int(rng.choice([0, 0, 2, 3])), keep_streams=bool(seed % 3 == 0))
+        except SdrxError as e:
+            assert "fs >= 1024" in str(e) or "last chunk shorter than 256" in str(e), (seed, str(e))
+            continue
+        nodes, roots = ob.build_tree("port", topo)
+        leaves = topo.leaves_in_publish_order()
+        lcg = synth.Lcg(100 + seed)
+        fno = 0
+        keepalive = []
+
+        def next_frame(as_bytes=False):
+            nonlocal fno
+            iq = synth.lcg_frame(topo.frame, lcg)
+            if as_bytes:
+                b = np.clip(np.rint(iq) + 127, 0, 255).astype(np.uint8)
+                iq = ob.u8_to_float(b)
+            else:
+                b = None
+                iq = iq + synth.tone_frame(topo.frame, topo.fs, [(topo.fs / 7.3, 20.0)], fno * topo.frame)
+            ob.process_roots(roots, iq)
+            fno += 1
+            want = [(nodes[i].usb() if topo.vfos[i].demod_usb else nodes[i].iq()).copy() for i in leaves]
+            return iq, b, want
+
+        def check(want, ctx, streams):
+            for k, i in enumerate(leaves):
+                assert np.array_equal(rx.output(i), want[k]), (seed, ctx, i, "payload")
+            if streams:  # (the oracle's streams are those of the LAST frame fed: only right after a synchronous delivery of it)
+                for i in range(len(topo.vfos)):
+                    got = rx.stream(i, missing_ok=True)
+                    assert got is None or np.array_equal(bits(got), bits(nodes[i].stream())), (seed, ctx, i, "stream")
+
+        for step in range(int(rng.integers(5, 10))):
+            kind = rng.choice(["process", "u8", "pipelined", "device", "tap"], p=[0.25, 0.15, 0.25, 0.3, 0.05])
+            ctx = (step, str(kind))
+            if kind == "process":
+                iq, _, want = next_frame()
+                rx.process(iq)
+                check(want, ctx, True)
+            elif kind == "u8":
+                iq, b, want = next_frame(as_bytes=True)
+                rx.process_u8(b)
+                check(want, ctx, True)
+            elif kind == "pipelined":
+                k = int(rng.integers(2, 6))
+                wants = []
+                iq, _, w = next_frame()
+                rx.submit(iq)
+                wants.append(w)
+                for _ in range(k - 1):
+                    iq, _, w = next_frame()
+                    rx.submit(iq)
+                    wants.append(w)
+                    if rng.random() < 0.7 or rx.in_flight() == 2:
+                        rx.wait()
+                        check(wants.pop(0), ctx, False)
+                while wants:
+                    rx.wait()
+                    check(wants.pop(0), ctx, not wants)
+            elif kind == "device":
+                k = int(rng.integers(1, 5))
+                for q in range(k):
+                    iq, _, want = next_frame()
+                    d = torch.from_numpy(iq).cuda()
+                    torch.cuda.synchronize()
+                    keepalive.append(d)
+                    rx.process_device(d.data_ptr(), topo.frame)
+                    if rng.random() < 0.25:
+                        rx.sync()
+                rx.fetch()
+                check(want, ctx, True)
+            else:
+                rx.set_tap(int(rng.integers(-1, len(topo.vfos))))
+        rx.close()
+        ran += 1
+    assert ran >= N_SEEDS * 55 // 60, ran
+
+
 def test_fused_late_decimation_random_geometries(Receiver):
     """The /5 and /6 walks on frames of 960 .. 11 520 samples that are NOT multiples of their 960 / 1008-sample chunks
     (partial last chunks of every length that is a multiple of 16 L), below mains of depth 0-2, with and without the audio
