@@ -1063,6 +1063,86 @@ def test_random_api_sequences_on_random_trees(Receiver):
     assert ran >= N_SEEDS * 55 // 60, ran
 
 
+def test_random_api_sequences_on_a_device_list():
+    """The same on sdrx_group_*: the random trees sharded over 2-5 members (on the one GPU of the test box), fed through
+    sdrx_group_process, _process_u8 (with the DC-bias removal for every second tree: each member runs the recurrence itself),
+    the pipelined _submit / _wait pair and _process_device + _sync in random order.  What the publish callback delivers --
+    topic, rate, payload, in the reference's order over the WHOLE tree -- is the oracle's for the delivered frame."""
+    import torch
+    from sdrreceiver_amd.receiver import Group, SdrxError
+    ran = 0
+    for seed in range(max(20, N_SEEDS // 2)):
+        rng = np.random.default_rng(9000 + seed)
+        topo = _random_topology(np.random.default_rng(1000 + seed))
+        members = int(rng.integers(2, 6))
+        try:
+            g = Group.from_topology(topo, [0] * members)
+        except SdrxError as e:
+            assert "fs >= 1024" in str(e) or "last chunk shorter than 256" in str(e), (seed, str(e))
+            continue
+        nodes, roots = ob.build_tree("port", topo)
+        order = topo.leaves_in_publish_order()
+        lcg = synth.Lcg(300 + seed)
+        dc = bool(seed % 2)
+        state = np.zeros(2, np.float32)
+        keepalive = []
+
+        def frame(as_bytes):
+            iq = synth.lcg_frame(topo.frame, lcg)
+            b = None
+            if as_bytes:
+                b = np.clip(np.rint(iq) + 130, 0, 255).astype(np.uint8)
+                iq = ob.u8_to_float(b)
+                if dc:
+                    ob.dc_correct(iq, state)
+            ob.process_roots(roots, iq)
+            want = [(topo.vfos[i].topic.encode()[:5].ljust(5, b"\0"), topo.vfos[i].output_rate,
+                     (nodes[i].usb() if topo.vfos[i].demod_usb else nodes[i].iq()).tobytes()) for i in order
+                    if topo.vfos[i].demod_usb or topo.vfos[i].topic]
+            return iq, b, want
+
+        for step in range(int(rng.integers(4, 8))):
+            kind = rng.choice(["process", "u8", "pipelined", "pipelined_u8", "device"])
+            ctx = (seed, members, step, str(kind))
+            if kind == "process":
+                iq, _, want = frame(False)
+                g.process(iq)
+                assert g.published == want, ctx
+            elif kind == "u8":
+                _, b, want = frame(True)
+                g.process_u8(b, correct_dc=dc)
+                assert g.published == want, ctx
+            elif kind in ("pipelined", "pipelined_u8"):
+                wants = []
+                for q in range(int(rng.integers(2, 5))):
+                    iq, b, w = frame(kind == "pipelined_u8")
+                    if b is None:
+                        g.submit(iq)
+                    else:
+                        g.submit_u8(b, correct_dc=dc)
+                    wants.append(w)
+                    if g.in_flight() == 2 or rng.random() < 0.5:
+                        g.wait()
+                        assert g.published == wants.pop(0), ctx
+                while wants:
+                    g.wait()
+                    assert g.published == wants.pop(0), ctx
+            else:
+                for q in range(int(rng.integers(1, 4))):
+                    iq, _, want = frame(False)
+                    d = torch.from_numpy(iq).cuda()
+                    torch.cuda.synchronize()
+                    keepalive.append(d)
+                    g.process_device(d.data_ptr(), topo.frame)
+                g.sync()
+                for i in order:
+                    ref = nodes[i].usb() if topo.vfos[i].demod_usb else nodes[i].iq()
+                    assert np.array_equal(g.output(i), ref), (ctx, i)
+        g.close()
+        ran += 1
+    assert ran >= max(20, N_SEEDS // 2) * 5 // 6, ran
+
+
 def test_fused_late_decimation_random_geometries(Receiver):
     """The /5 and /6 walks on frames of 960 .. 11 520 samples that are NOT multiples of their 960 / 1008-sample chunks
     (partial last chunks of every length that is a multiple of 16 L), below mains of depth 0-2, with and without the audio
