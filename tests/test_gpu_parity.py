@@ -971,6 +971,28 @@ def test_frame_pipeline_on_random_trees(Receiver, mode):
     assert ran >= N_SEEDS * 55 // 60, ran
 
 
+def test_fast_mode_on_random_trees(Receiver):
+    """The A/B arithmetic (exact=0: FMAs) on the random trees, three frames with tones: every stream, every pre-quantisation
+    float within 1e-5 of max|ref|, int16 within one LSB -- the north-star tolerance, on trees nobody tuned it for."""
+    from sdrreceiver_amd.receiver import SdrxError
+    ran = 0
+    for seed in range(max(20, N_SEEDS // 2)):
+        topo = _random_topology(np.random.default_rng(1000 + seed))
+        try:
+            rx = Receiver.from_topology(topo, exact=False, keep_prequant=True, keep_streams=True, segments=seed % 3)
+        except SdrxError as e:
+            assert "fs >= 1024" in str(e) or "last chunk shorter than 256" in str(e), (seed, str(e))
+            continue
+        nodes, roots = ob.build_tree("port", topo)
+        for f, iq in _frames(topo, 3, seed=seed, tones=[(topo.fs / 7.3, 20.0), (-topo.fs / 3.1, 9.0)]):
+            rx.process(iq)
+            ob.process_roots(roots, iq)
+            _check_tolerance(rx, nodes, topo, ("fast random", seed, f))
+        rx.close()
+        ran += 1
+    assert ran >= max(20, N_SEEDS // 2) * 5 // 6, ran
+
+
 def test_random_api_sequences_on_random_trees(Receiver):
     """The per-frame entry points mixed at random on the random trees: sdrx_process, sdrx_process_u8, the pipelined pair
     sdrx_submit / sdrx_wait (one or two frames in flight), sdrx_process_device queued 1-4 deep with one sdrx_fetch, an
