@@ -111,8 +111,9 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
  *   "keep_streams" 0 (default) | 1: every such leaf also keeps decimate[0] of every frame (parity tests that
  *            compare every stream of the tree).
  *   "dc_blocked_scan" 0|1 (default 0): how sdrx_process_u8 removes the DC bias.  0 = the
- *                 reference's sequentially rounded fp32 recurrence, bit for bit (one workgroup,
- *                 ~4.5 ms per 384 000-sample frame).  1 = the same linear filter as a blocked
+ *                 reference's sequentially rounded fp32 recurrence, bit for bit (~2.0 ms per
+ *                 384 000-sample frame: two waves, each alone with its dependent chain, between a
+ *                 parallel products and a parallel apply kernel).  1 = the same linear filter as a blocked
  *                 parallel scan (~15 us): the true IIR response.  The reference's recurrence
  *                 wanders around that by up to ~3e-3 of the DC offset (its rounding errors are
  *                 correlated from step to step), so 1 is NOT within the 1e-5 parity tolerance

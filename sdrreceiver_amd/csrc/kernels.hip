@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_ingest_u8(const unsigned *__restrict__ 
 //                                                                            scalar operands, a group ahead), the 64 chain
 //                                                                            operations, ONE 8-byte store
 //   k_dc_apply      (parallel)  replays the 16 steps behind each A[c][j], curr - avept, tile layout
-// Measured: 2.3 ms per 384 000-sample frame (4.5 ms for the one-workgroup pipeline of round 3, 9.3 ms for the one-wave
+// Measured: 2.03 ms per 384 000-sample frame (4.5 ms for the one-workgroup pipeline of round 3, 9.3 ms for the one-wave
 // version of rounds 1-2); the floor of the recurrence itself is 384 000 x 12.25 cycles = 1.96 ms at 2.4 GHz.
 typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr int kDcPad = 32 * 16 + 128; // floats behind the last sample of P / A: the chain's scalar prefetch runs two groups ahead, its line prefetch kDcAhead
