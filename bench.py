@@ -8,13 +8,14 @@
 A "step" is one pass of the hot path over one raw IQ frame (250 ms of signal: 384 000 cf32 at
 1.536 MS/s), already resident in HBM, through every VFO of the workload.
 
-Workload.  N = 1 (the BENCH line): BASELINE.json config 3 -- the two sdr_25E main VFOs with 512
-sub VFOs each (1 024 sub VFOs; main0 subs 384 k -> 12 k, main1 subs 192 k -> 48 k, every 2nd with
-the 47-tap 10 kHz low-pass).  N > 1 (the SCALE lines): BASELINE.json config 5 -- the same tree
-with 65 536 sub VFOs IN TOTAL, sharded over the N GPUs (strong scaling: 65 536 / N per GPU,
-mains replicated), raw frames broadcast from rank 0 over RCCL; the weak-scaled config-3 reading
-(1 024 sub VFOs per GPU) is measured in the same run and reported as the side object
-`weak_config3`.  `--workload` overrides either default.
+Workload.  BASELINE.json config 3 PER GPU -- the two sdr_25E main VFOs with 512 sub VFOs each (1 024 sub
+VFOs; main0 subs 384 k -> 12 k, main1 subs 192 k -> 48 k, every 2nd with the 47-tap 10 kHz low-pass).
+N = 1 is the BENCH line; at N > 1 (the SCALE lines) the tree has N x 1 024 sub VFOs, sharded over the N
+GPUs (mains replicated), raw frames broadcast from rank 0 over RCCL: the path partitions, per-GPU work
+is fixed, `scaling` is "weak", and `value` at N is directly comparable with N x the N = 1 value.
+BASELINE.json config 5 -- the same tree with 65 536 sub VFOs IN TOTAL (strong scaling: 65 536 / N per
+GPU) -- is measured in the same run and reported as the side object `config5_strong`.  `--workload`
+overrides the default (with `--workload config5` the roles swap: side object `weak_config3`).
 
 Timing.  W untimed warm-up steps (plus enough extra to reach ~50 ms of GPU time: the clock ramps),
 then the timed region -- EXACTLY K steps between barrier + torch.cuda.synchronize() on both sides,
@@ -274,7 +275,7 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libsdrx has no CPU fallback)")
-    workload = args.workload or ("config3" if world == 1 else "config5")
+    workload = args.workload or "config3"
     # SDRX_BENCH_SHARE_GPU=1 (validation on a 1-GPU box only): all ranks on device 0, gloo instead of
     # RCCL (which refuses two ranks on one device).  The numbers of such a run mean nothing.
     share = os.environ.get("SDRX_BENCH_SHARE_GPU") == "1"
@@ -564,18 +565,22 @@ def main():
                       "transmit_usb + ZmqPublisher::publish) included; one context per main VFO")
         abi["qt_adapter"] = qt
 
-    weak = None
-    if world > 1 and workload == "config5":
-        # side reading: the weak-scaled config-3 workload (1 024 sub VFOs per GPU), the N = 1 BENCH workload
+    weak, other_key = None, None
+    if world > 1 and workload in ("config3", "config5") and not args.no_side:
+        # side reading at N > 1: the other of the two multi-GPU workloads -- BASELINE config 5 (65 536 sub VFOs in total, strong
+        # scaling) next to the weak-scaled default, or the other way round with --workload config5
+        other, other_key, other_scaling = (("config5", "config5_strong", "strong") if workload == "config3" else
+                                           ("config3", "weak_config3", "weak"))
         job.close()
         job = None
         try:
-            wj = Job("config3")
+            wj = Job(other)
             wreps = wj.measure(args.steps, args.warmup, max(1, min(args.reps, 7)))
             wdt = statistics.median(wreps)
             ws, wa, wl = allsum([wj.st["vfo_samples_per_frame"], wj.st["algorithmic_bytes_per_frame"], wj.st["n_leaves"]])
-            weak = {"workload": wj.descr, "scaling": "weak", "ms_per_step": round(wdt / args.steps * 1e3, 4),
+            weak = {"workload": wj.descr, "scaling": other_scaling, "ms_per_step": round(wdt / args.steps * 1e3, 4),
                     "value": round(args.steps * ws / wdt / 1e6, 2), "unit": "MSamples/s",
+                    "realtime_factor": round((wj.full.frame / wj.full.fs) / (wdt / args.steps), 1),
                     "algorithmic_GBps_whole_job": round(args.steps * wa / wdt / 1e9, 1), "sub_vfos_total": int(wl)}
             wj.close()
         except Exception as e:
@@ -624,7 +629,7 @@ def main():
             out["rccl_world"] = diag_world  # the world size the collective library reports ...
             out["peer_ok"] = diag_peer      # ... and per rank: can its device reach rank 0's directly (hipDeviceCanAccessPeer)?
         if weak:
-            out["weak_config3"] = weak
+            out[other_key] = weak
         if side:
             out.update(side)
         if world == 1 and args.configs1:

@@ -62,10 +62,12 @@ def test_two_ranks_config5_shaped_tree():
 @pytest.mark.gpu
 def test_bench_eight_ranks_dry_run_on_one_gpu():
     """What the driver's SCALE run launches at N = 8 -- `python -m torch.distributed.run --nproc-per-node 8
-    bench.py --gpus 8` on the FULL config 5 (65 536 sub VFOs, 8 192 per rank, mains replicated, 4 frames
-    per broadcast) -- with all eight ranks on the one GPU of the test box (SDRX_BENCH_SHARE_GPU=1: gloo
-    instead of RCCL, numbers meaningless).  The shapes, the sharding, the broadcast batching, the strong /
-    weak bookkeeping and the JSON line are exactly those of the real run; only the transport differs."""
+    bench.py --gpus 8`: the weak-scaled config 3 (1 024 sub VFOs per rank, mains replicated, 4 frames per
+    broadcast) as the line's own workload and the FULL config 5 (65 536 sub VFOs, 8 192 per rank: strong
+    scaling) as its side object -- with all eight ranks on the one GPU of the test box
+    (SDRX_BENCH_SHARE_GPU=1: gloo instead of RCCL, numbers meaningless).  The shapes, the sharding, the
+    broadcast batching, the weak / strong bookkeeping, the self-diagnosis fields and the JSON line are exactly
+    those of the real run; only the transport differs."""
     import json
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -78,11 +80,12 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["steps"] == 8
-    assert out["config"]["sub_vfos_per_gpu"] == 8192 and out["config"]["vfos_total"] == 65536 + 2
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["steps"] == 8
+    assert out["config"]["sub_vfos_per_gpu"] == 1024 and out["config"]["vfos_total"] == 8 * 1024 + 2
     assert out["value"] > 0 and out["ms_per_step"] > 0
-    w = out["weak_config3"]
-    assert "error" not in w and w["scaling"] == "weak" and w["sub_vfos_total"] == 8 * 1024 and w["value"] > 0
+    assert out["rccl_world"] == 8 and out["peer_ok"] == [1] * 8
+    w = out["config5_strong"]
+    assert "error" not in w and w["scaling"] == "strong" and w["sub_vfos_total"] == 65536 and w["value"] > 0
 
 
 @pytest.mark.gpu
