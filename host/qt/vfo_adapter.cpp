@@ -19,7 +19,8 @@
 //     deleting a root (MainWindow's stop, vfo.cpp:34-59) frees its context -- the next start builds a
 //     new one;
 //   * every leaf's payload comes back through the library's publish callback in the reference's order
-//     and goes out through transmitData() -> the unchanged ZmqPublisher::publish;
+//     and goes out through the publisher transmitData() would pick -> the unchanged ZmqPublisher::publish, straight from
+//     the library's pinned buffer (no copy into the private transmit_usb / transmit_iq: zmq_send copies anyway);
 //   * fftData carries decimate[decimateCount] of the node fftVFOSlot selected (vfo.cpp:290-293).
 //
 // Device selection (environment, read when a tree is committed): SDRX_DEVICE=<ordinal> (default 0), or
@@ -311,8 +312,10 @@ void vfo::process(const std::vector<cpx_typef> &samples)
             }
         };
         Walk::add(*T, T, this, -1);
-        // a lambda inside a member function may touch private members: the payload lands in the
-        // object's own transmit buffer and leaves through its own transmitData()
+        // a lambda inside a member function may touch private members: the payload leaves through the publisher
+        // transmitData() would pick (vfo.cpp:426-453), straight from the library's pinned host buffer -- zmq_send copies
+        // what it is handed (zmqpublisher.cpp:91-93), and transmit_usb / transmit_iq are private members nobody else reads,
+        // so the 15 MB per frame (config 3) are not copied into them first: that copy was two thirds of a frame's host time
         sdrx_publish_fn deliver = [](void *user, const char *, uint32_t, const void *buf, uint32_t len) {
             Tree &T = *static_cast<Tree *>(user);
             // leaves that publish nothing (non-USB without a topic) are skipped by the library too
@@ -321,11 +324,9 @@ void vfo::process(const std::vector<cpx_typef> &samples)
             if (T.cursor >= T.leaves.size())
                 return;
             vfo *v = T.leaves[T.cursor++];
-            if (v->demodUSB)
-                v->transmit_usb.assign((const short *)buf, (const short *)buf + len / sizeof(short));
-            else
-                v->transmit_iq.assign((const signed char *)buf, (const signed char *)buf + len);
-            v->transmitData();
+            ZmqPublisher &pub = v->zmqBind ? vfo::bind_publisher : v->connect_publisher;
+            if (v->demodUSB || v->zmqTopic.length() > 0)
+                pub.publish(static_cast<unsigned char *>(const_cast<void *>(buf)), len, v->zmqTopic, v->outputRate);
         };
         if (T->grp)
             sdrx_group_set_publish_callback(T->grp, deliver, T.get());
