@@ -161,3 +161,31 @@ def test_adapter_processes_what_it_is_handed(mutate, mode):
     assert len(got) == len(want)
     for g, w in zip(got, want):
         assert g == w
+
+
+@pytest.mark.gpu
+def test_adapter_on_random_trees():
+    """The seeded random trees of tests/test_gpu_parity.py (1-3 levels, depths 0-4, USB and IQ leaves, late decimation,
+    partial last chunks) behind the unmodified vfo.h: the reference's sources and the adapter, the same client, three
+    frames, an fftData tap on the tree's last leaf: byte-identical subscriber streams and fftData logs.  Trees the
+    library refuses for a documented restriction (a rate below 1024 Hz ...) are skipped: the adapter reports them at the
+    first process() and exits."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdropin_ref.so")):
+        pytest.skip("oracle/_ref/libdropin_ref.so not built (make -C host/qt needs /root/reference)")
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from sdrreceiver_amd import topology as tp
+    n = max(3, int(os.environ.get("SDRX_TEST_SEEDS", "60")) // 20)
+    ran = 0
+    for seed in range(n):
+        topo = tp.random_topology(np.random.default_rng(1000 + seed))
+        if any(v.fs < 1024 or 0 < v.samples_per_buffer % 1024 < 256 for v in topo.vfos):
+            continue
+        fft = next((v.topic for v in reversed(topo.vfos) if v.topic), "")
+        want = _raw("ref", f"random:{seed}", 3, fft, {})
+        got = _raw("sdrx", f"random:{seed}", 3, fft, {"SDRX_PIPELINE": "1"} if seed % 2 else {})
+        assert len(got) == len(want) and len(want) > 0, (seed, len(got), len(want))
+        for g, w in zip(got, want):
+            assert g == w, (seed, g, w)
+        ran += 1
+    assert ran >= 2

@@ -34,6 +34,9 @@ def topology(name):
         return tp.profile_25e()
     if name == "config4_12":
         return tp.config4(12)
+    if name.startswith("random:"):  # the seeded random trees of tests/test_gpu_parity.py
+        import numpy as np
+        return tp.random_topology(np.random.default_rng(1000 + int(name.split(":")[1])))
     raise SystemExit(f"unknown topology {name}")
 
 
