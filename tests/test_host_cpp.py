@@ -231,3 +231,34 @@ def test_cpp_host_fft_taps(tmp_path):
     assert run("--fft", "VFO19") == want_vfo
     assert run("--fft", "Main") == want_raw
     assert run("--fft", "NOSUCH") == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [None, "0,0"])
+def test_cpp_host_fft_tap_on_a_fused_late_decimation(devices, tmp_path):
+    """The 54W-like profile: VFO51 / VFO52 are /5 leaves with decimate_count 0 -- their low-pass runs inside the mix wave
+    and decimate[0] exists only while the leaf is the tap.  host/sdrx_host.hpp names the selected VFO to the library before
+    the frame (sdrx_set_tap), on one device and over a device list: the fftData log equals the stream an oracle-checked
+    Receiver with that tap returns, the published messages do not change."""
+    from sdrreceiver_amd.receiver import Receiver
+    _build()
+    p = tmp_path / "profile.ini"
+    p.write_text(INI_54W_LIKE)
+    topo = tp.topology_from_ini(INI_54W_LIKE)
+    vid = [i for i, v in enumerate(topo.vfos) if v.topic == "VFO52"][0]
+    assert topo.vfos[vid].late_decimate == 5 and topo.vfos[vid].decimate_count == 0
+    rx = Receiver.from_topology(topo)
+    rx.set_tap(vid)
+    lcg = synth.Lcg(1)
+    want = []
+    for f in range(4):
+        iq = synth.lcg_frame(topo.frame, lcg)
+        rx.process(iq)
+        st = rx.stream(vid)
+        want.append(["fft", str(f), "VFO52", str(st.size), f"{_fnv1a(st.tobytes()):016x}"])
+    rx.close()
+    extra = ["--devices", devices] if devices else []
+    out = subprocess.check_output([DEMO, str(p), "--frames", "4", "--fft", "VFO52", *extra], text=True).splitlines()
+    plain = subprocess.check_output([DEMO, str(p), "--frames", "4", *extra], text=True).splitlines()
+    assert [l.split() for l in out if l.startswith("fft ")] == want
+    assert [l for l in out if not l.startswith("fft ")] == plain
