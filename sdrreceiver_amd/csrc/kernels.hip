@@ -584,75 +584,11 @@ __host__ __device__ constexpr int stage_offset(int s) // float2 index of A_s, s 
 }
 __host__ __device__ constexpr int pad0(int p) { return p + 2 * (p >> 4); }
 constexpr int kTransposeElems = kChunk + 2 * (kChunk >> 4); // 1152 float2
-// LDS-DMA prefetch of the input tiles (global_load_lds_dwordx4: HBM/L2 -> LDS with no VGPR in between, issued one
-// half-tile or one tile ahead of its use).  SDRX_GLDS = 0: off (8 plain 16-byte loads per lane at the top of every
-// chunk); 1: a 4 KiB slot = half a tile, refilled twice per chunk; 2: an 8 KiB slot = the whole next tile.
-#ifndef SDRX_GLDS
-#define SDRX_GLDS 0
-#endif
-constexpr int kGldsTileBytes = SDRX_GLDS == 1 ? 4096 : SDRX_GLDS == 2 ? 8192 : 0;
-constexpr int kGldsBytes = kGldsTileBytes + (SDRX_GLDS ? 512 : 0); // + the chunk's 64 NCO checkpoints as two planes of 64 floats
 __host__ __device__ constexpr int k1_lds_bytes(int d, bool need_transpose)
 {
     int stages = 8 * stage_offset(d < kRegStages ? kRegStages : d);
     int tr = need_transpose ? 8 * kTransposeElems : 0;
-    return kGldsBytes + kCarryBytes + (stages > tr ? stages : tr);
-}
-
-// N pieces of 1 KiB: piece k lands at LDS byte address lds_base + 1024 k + 16 lane (the instruction offset applies to
-// the global AND the LDS address; the destination is lane-linear = exactly the tile layout's [i2][lane] order) from
-// `src` + 1024 k bytes, a per-lane pointer.  Waits for the wave's earlier LDS reads first (the slot is being re-used).
-// The compiler does not know these loads: the data is ordered for a later ds_read only by glds_wait().
-template <int N>
-__device__ __forceinline__ void glds_issue(const float4 *src, unsigned lds_base)
-{
-    static_assert(N == 4 || N == 8, "half a tile or a tile");
-    unsigned keep;
-    if (N == 4)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(src), "s"(lds_base)
-                     : "memory");
-    else
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
-                     "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %2, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\t"
-                     "global_load_lds_dwordx4 %2, off offset:2048\n\tglobal_load_lds_dwordx4 %2, off offset:3072\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(src), "v"(src + 256), "s"(lds_base), "s"(lds_base + 4096u)
-                     : "memory");
-}
-// every LDS-DMA (and every other vector memory operation) this wave has issued is complete
-__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// "These values exist NOW": an empty volatile asm that reads and writes them.  Volatile asms keep their order, so
-// everything the values depend on is computed -- and every load they come from waited for -- before the next
-// glds_wait() / glds_issue(); without it the optimiser sinks the arithmetic that is meant to cover a DMA's latency
-// below the wait, and parks its own vmcnt waits for the level-0 loads behind a join the tile path runs through too.
-__device__ __forceinline__ void pin(v2f &a) { asm volatile("" : "+v"(a)); }
-template <int N>
-__device__ __forceinline__ void pin_all(v2f *a)
-{
-#pragma unroll
-    for (int i = 0; i < N; i += 4)
-        asm volatile("" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]));
-}
-// One float2 per lane (the lane's NCO checkpoint; `src` per lane) as two planes: re at lds_base + 4 lane, im at
-// lds_base + 256 + 4 lane.  (The second piece reads src + 4 bytes through the instruction offset, which also moves
-// its LDS address by 4: hence M0 = base + 252.)
-__device__ __forceinline__ void glds_issue_cp(const float2 *src, unsigned lds_base)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
-                 "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off offset:4\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src), "s"(lds_base), "s"(lds_base + 252u)
-                 : "memory");
+    return kCarryBytes + (stages > tr ? stages : tr);
 }
 
 // k_mix_decimate is ONE wave per workgroup and every LDS byte it touches is private to that wave.
@@ -676,11 +612,7 @@ __device__ __forceinline__ void hb_stage_lds(v2f *__restrict__ A, v2f *__restric
     wave_sync(); // stage input (written by the previous phase) is visible
     const int nout = cnt >> 1;
     for (int j = lane; j < nout; j += 64) {
-#ifndef SDRX_ABL_CONFLICT
         const v2f *w = A + kCarry + 2 * j - 10; // w[0..10], newest = input sample 2j of this chunk
-#else
-        const v2f *w = A + kCarry + j - 10 + (j >> 6); // ablation: lane stride 1 (conflict-free reads, wrong results)
-#endif
         const v2f y = hb_dot2<EXACT>(w[0], w[2], w[4], w[5], w[6], w[8], w[10]);
         if (!last)
             B[kCarry + j] = y;
@@ -792,12 +724,6 @@ template <bool EXACT>
 __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K1Work W, unsigned long long frame_no,
                                          const void *__restrict__ raw, int raw_mode, bool level0, unsigned char *smem, int lane)
 {
-#if SDRX_GLDS
-    const unsigned char *slot = smem; // the LDS-DMA landing area: (half) a tile, lane-linear like the tile itself ...
-    const float *cpl = reinterpret_cast<const float *>(smem + kGldsTileBytes); // ... and the chunk's checkpoints, [re 64 | im 64]
-    const unsigned slot_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem); // LDS byte address of `slot`
-    smem += kGldsBytes;
-#endif
     v2f *car0 = reinterpret_cast<v2f *>(smem);             // [8]
     v2f *car1 = car0 + 8;                                  // [8]
     v2f *lds = reinterpret_cast<v2f *>(smem + kCarryBytes);
@@ -833,35 +759,11 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
 
     // The item walks 1024-sample chunks from sample s_begin (any multiple of 16: a chunk need not
     // coincide with a tile of the input) and emits the outputs whose input position is >= s_first_out.
-#ifndef SDRX_ABL_STORE
     const int first_out = W.s_first_out;
-#else
-    const int first_out = D.n_in == 12345 ? W.s_first_out : 0x7fffffff; // ablation: nothing is ever emitted
-#endif
     const int lane16 = (W.s_begin >> 4) + lane; // this lane's run in the item's first chunk, in units of 16 samples
     // the lane's first 16-byte unit of the item as a 32-bit index (a frame has < 2^20 units): the loads below then take the
     // uniform stream pointer from SGPRs and one 32-bit VGPR offset instead of keeping a 64-bit pointer alive per lane
     const unsigned unit_item = (unsigned)(lane16 >> 6) * 512u + (unsigned)(lane16 & 63);
-#if SDRX_GLDS
-    const float4 *src_item = in + unit_item;
-#endif
-#if SDRX_GLDS
-    // items fed from a tile-layout stream (every sub VFO; a wide level 0) take their tiles through the LDS-DMA slot
-    const bool tile_in = !(level0 && raw_mode != kRawTiled);
-    // this lane's NCO checkpoint for the chunk at `b`: cp[idx >> 4], idx = table position of the lane's first sample
-    auto cp_of = [&](int b) {
-        int ix = phase_frame + b; // both < L
-        ix -= ix >= D.L ? D.L : 0;
-        ix += lane * kRun;        // L >= kChunk (checked by sdrx_finalize)
-        ix -= ix >= D.L ? D.L : 0;
-        return D.cp + (ix >> 4);
-    };
-    if (tile_in) {
-        glds_issue<SDRX_GLDS == 1 ? 4 : 8>(src_item, slot_lds);
-        glds_issue_cp(cp_of(W.s_begin), slot_lds + kGldsTileBytes);
-        glds_wait();
-    }
-#endif
     int pair_base = -1; // >= 0: the stage-2 outputs of the chunk at this position wait in A_3 for the next chunk's (SDRX_PAIR_STAGES)
     for (int base = W.s_begin; base < W.s_end; base += kChunk) {
         const int valid = min(kChunk, D.n_in - base);
@@ -871,9 +773,6 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         const bool save = base + valid == D.n_in;         // the chunk that holds the frame's last sample
         const int lv = (valid >> 4) - 1; // last lane holding real samples
         const bool active = lane <= lv;
-#if SDRX_GLDS
-        v2f o_lds = zero2;
-#endif
 
         // 1. this lane's run of 16 consecutive samples: 8 coalesced 16-byte loads
         v2f ext0[10 + kRun]; // ext0[10 + t] = x[t]; ext0[0..9] = halo x[-10..-1]
@@ -890,9 +789,6 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
                 x[2 * i] = lo2(v);
                 x[2 * i + 1] = hi2(v);
             }
-#if SDRX_GLDS
-            pin_all<16>(x);
-#endif
         } else if (level0 && raw_mode == kRawU8) {
             // dongle bytes: floats[b] = b - 127 (jonti/sdr.cpp:43-49), 32 bytes per lane
             const v4u *nat = reinterpret_cast<const v4u *>(raw) + (size_t)p16 * 2;
@@ -909,57 +805,18 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
                     x[8 * h + 2 * k + 1] = b;
                 }
             }
-#if SDRX_GLDS
-            pin_all<16>(x);
-#endif
         } else {
             // The lane's position inside its tile is the same in every chunk of the item (the walk
             // advances by exactly one tile per chunk): src_item is computed once, a chunk adds 512
             // units.  A shifted walk straddles two tiles; its idle lanes in the frame's last chunk may
             // read the (zero) tile behind the last one, which every tile-layout buffer has.
-#if SDRX_GLDS
-            const float4 *src = src_item + (size_t)((base - W.s_begin) >> 10) * 512;
-#else
             const float4 *src = in + (unit_item + (unsigned)((base - W.s_begin) >> 10) * 512u);
-#endif
-#if SDRX_GLDS == 0
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-#ifndef SDRX_ABL_LOAD
                 const v4f v = gldv4(src + 64 * i); // tile_unit(c, i, l) = tile_unit(c, 0, l) + 64 i
-#else
-                v4f v = {1.f * lane, 2.f, 3.f * base, 4.f * i}; // ablation: no global loads
-                asm volatile("" : "+v"(v));
-#endif
                 x[2 * i] = lo2(v);
                 x[2 * i + 1] = hi2(v);
             }
-#elif SDRX_GLDS == 1
-            // the first half of the tile landed in the slot during the previous chunk (and was waited for there);
-            // its second half is requested as soon as these reads are back, and used after 8 NCO / mix steps
-            const v4f *sl = reinterpret_cast<const v4f *>(slot) + lane;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const v4f v = sl[64 * i];
-                x[2 * i] = lo2(v);
-                x[2 * i + 1] = hi2(v);
-            }
-            o_lds = v2f{cpl[lane], cpl[64 + lane]};
-            glds_issue<4>(src + 256, slot_lds);
-#else
-            const v4f *sl = reinterpret_cast<const v4f *>(slot) + lane;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const v4f v = sl[64 * i];
-                x[2 * i] = lo2(v);
-                x[2 * i + 1] = hi2(v);
-            }
-            o_lds = v2f{cpl[lane], cpl[64 + lane]};
-            if (base + kChunk < W.s_end) { // the whole next tile and its checkpoints travel while this one is worked on
-                glds_issue<8>(src + 512, slot_lds);
-                glds_issue_cp(cp_of(base + kChunk), slot_lds + kGldsTileBytes);
-            }
-#endif
         }
 
         // 2. NCO: regenerate table[idx .. idx+16) from the checkpoint before it, and mix
@@ -969,85 +826,18 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         idx -= idx >= D.L ? D.L : 0;
         idx += lane * kRun;           // L >= kChunk (checked by sdrx_finalize)
         idx -= idx >= D.L ? D.L : 0;
-#if SDRX_GLDS
-        v2f o = o_lds;
-        if (!tile_in) {
-            o = gldv2(D.cp + (idx >> 4));
-            asm volatile("" : "+v"(o)); // the wait for this load stays inside the branch (at the join it would drain the DMA)
-        }
-#else
         v2f o = gldv2(D.cp + (idx >> 4));
-#endif
-#if !SDRX_GLDS
         const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
-#endif
 #pragma unroll
         for (int i = 0; i < kRun; ++i) {
-#if SDRX_GLDS == 1
-            if (i == kRun / 2) { // the 8 steps above are the latency cover of the DMA: they stay above
-                pin(o);
-                pin_all<8>(x);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (i == kRun / 2 && tile_in) {
-                // second half of the tile: requested at the top of the chunk, 8 NCO / mix steps ago
-                glds_wait();
-                const v4f *sl = reinterpret_cast<const v4f *>(slot) + lane;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const v4f v = sl[64 * q];
-                    x[8 + 2 * q] = lo2(v);
-                    x[8 + 2 * q + 1] = hi2(v);
-                }
-                if (base + kChunk < W.s_end) { // first half of the NEXT tile + its checkpoints: used a whole chunk later
-                    glds_issue<4>(src_item + (size_t)(((base - W.s_begin) >> 10) + 1) * 512, slot_lds);
-                    glds_issue_cp(cp_of(base + kChunk), slot_lds + kGldsTileBytes);
-                }
-            }
-#endif
-#ifndef SDRX_ABL_NCO
             o = nco_step_pk(o, rot);
-#else
-            asm volatile("" : "+v"(o)); // ablation: keep the value opaque, skip the recurrence
-#endif
             v2f m = o;
-#if SDRX_GLDS
-            if (i == 0 && frame_no == 0 && base == 0) { // (a scalar load: no vmcnt wait near the DMAs in flight)
-                const v2f last = {ldc(&D.cp[D.L >> 4].x), ldc(&D.cp[D.L >> 4].y)};
-                if (lane == 0)
-                    m = last;
-            }
-#else
             if (i == 0 && first_ever)
                 m = gldv2(D.cp + (D.L >> 4));
-#endif
-#ifndef SDRX_ABL_MIX
             x[i] = cmul(m, x[i]);
-#else
-            x[i] = x[i] + m;
-#endif
         }
 
-#if SDRX_GLDS
-        // The DMA for the next chunk was issued BEFORE this chunk's stores and is waited for before them too: at that
-        // point everything outstanding is old (the previous chunk's stores, a DMA that had the whole arithmetic of
-        // this chunk to land), and the stores themselves are never waited for (vmcnt counts loads and stores in order)
-#define GLDS_PRE_STORE()                                                                                  \
-    do {                                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        if (tile_in)                                                                                      \
-            glds_wait();                                                                                  \
-    } while (0)
-#else
-#define GLDS_PRE_STORE() \
-    do {                 \
-    } while (0)
-#endif
         if (D.d == 0) {
-#if SDRX_GLDS
-            pin_all<16>(x);
-#endif
-            GLDS_PRE_STORE();
             // no decimation: decimate[0] is the mixed stream itself
             if (D.out_tiled) {
                 if (emit_l && active) {
@@ -1080,7 +870,6 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
 
         // 3. stage 0 in registers.  Halo = the previous lane's x[6,8,10,11,12,13,14,15]
         //    (one whole-wave DPP shift each); lane 0 takes the previous chunk's lane 63 from LDS.
-#ifndef SDRX_ABL_CARRY
         wave_sync(); // car0/car1 of the previous chunk (or the initial state) are visible
         {
             const v4f *c4 = reinterpret_cast<const v4f *>(car0); // broadcast reads
@@ -1103,28 +892,15 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
             c4[2] = cat2(x[12], x[13]);
             c4[3] = cat2(x[14], x[15]);
         }
-#else
-        for (int q = 0; q < 10; ++q) ext0[q] = x[q]; // ablation: no LDS carry, no DPP
-#endif
         v2f ext1[10 + 8]; // ext1[10 + t] = y[t] (stage-0 outputs of this lane), ext1[0..9] halo
         v2f *y = ext1 + 10;
-#ifndef SDRX_ABL_ST0
         hb_regs<EXACT, 8>(ext0, y);
-#else
-#pragma unroll
-        for (int j = 0; j < 8; ++j) // ablation: 1 add instead of the 11-op dot
-            y[j] = ext0[2 * j] + ext0[2 * j + 10];
-#endif
         if (save && lane == lv) // next frame's stage-0 history: x[size-1-k], k = 1..10
 #pragma unroll
             for (int k = 1; k <= kHbHist; ++k)
                 gstv2(hb_save + 0 * kHbHist + k - 1, x[15 - k]);
 
         if (D.d == 1) {
-#if SDRX_GLDS
-            pin_all<8>(y);
-#endif
-            GLDS_PRE_STORE();
             if (emit_l && active) {
                 const int g = (base >> 1) + lane * 8;
 #pragma unroll
@@ -1136,7 +912,6 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
             continue;
         }
 
-#ifndef SDRX_ABL_CARRY
         // 4. stage 1 in registers.  Halo y[-8,-6,-5,-4,-3,-2,-1] = previous lane's y[0,2..7],
         //    y[-10] = the lane before that one's y[6] (a second shift of the shifted y[6]).
         {
@@ -1162,9 +937,6 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         }
         if (lane == 62)
             car1[0] = y[6];
-#else
-        for (int q = 0; q < 10; ++q) ext1[q] = y[q & 7];
-#endif
         if (save) { // next frame's stage-1 history: y[size1-1-k]
             if (lane == lv)
 #pragma unroll
@@ -1176,19 +948,9 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
                     gstv2(hb_save + 1 * kHbHist + k - 1, y[15 - k]);
         }
         v2f z[4];
-#ifndef SDRX_ABL_ST1
         hb_regs<EXACT, 4>(ext1, z);
-#else
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            z[j] = ext1[2 * j] + ext1[2 * j + 10];
-#endif
 
         if (D.d == 2) {
-#if SDRX_GLDS
-            pin_all<4>(z);
-#endif
-            GLDS_PRE_STORE();
             if (emit_l && active) {
                 const int g = (base >> 2) + lane * 4;
 #pragma unroll
@@ -1208,12 +970,7 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
             *reinterpret_cast<v4f *>(A2) = cat2(z[0], z[1]);
             *reinterpret_cast<v4f *>(A2 + 2) = cat2(z[2], z[3]);
         }
-#ifdef SDRX_ABL_LDS
-        if (emit && lane < 32) // ablation: skip the LDS stages, write something that depends on z
-            gstv2(out + (base >> D.d) + lane, z[0] + z[1] + z[2] + z[3]);
-        continue;
-#endif
-#if SDRX_FIXED_STAGES && !SDRX_GLDS
+#if SDRX_FIXED_STAGES
         if (valid == kChunk && !save && !D.out_tiled && D.d == kFixedDepth) { // (uniform) a full chunk of a leaf, not the frame's last
 #if SDRX_PAIR_STAGES
             // stage 2 every chunk; stages 3 and 4 every second chunk on both chunks' stage-2 outputs -- when the NEXT chunk
@@ -1237,13 +994,10 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         }
 #endif
         for (int s = kRegStages; s < D.d; ++s) {
-            if (s + 1 == D.d)
-                GLDS_PRE_STORE();
             hb_stage_lds<EXACT>(lds + stage_offset(s), lds + stage_offset(s + 1), out, base >> D.d, D.out_tiled != 0, s + 1 == D.d,
                                 max(0, (first_out - base) >> D.d), valid >> s, lane, save, hb_save + s * kHbHist);
         }
     }
-#undef GLDS_PRE_STORE
 }
 
 // ------------------------------------------------------------------------------------ late_item
