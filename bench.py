@@ -121,6 +121,87 @@ def cpu_baseline(workload):
     return out
 
 
+class Verifier:
+    """Checks WHAT WAS TIMED: the launch sequence of the timed region (sdrx_process_device back to back on the torch stream:
+    one k_mix_levels launch per step, level l on frame k - l, + the leaf tail of the frame that left the last level) at the
+    benchmarked size.  After every timed repetition -- outside the region -- `checkpoint()` fetches the payloads of the frame
+    processed last (sdrx_fetch: completes what is queued, copies the payloads out) and keeps those of a seeded sample of
+    leaves (topology.sample_leaves: first / last leaf of every shard block of every main + >= 64 random ones), then queues
+    one untimed frame so that the next region starts from the same steady pipeline state.  `finish()` runs the plain-C
+    oracle (oracle/vfo_oracle.c, the checker -- never the thing measured) over EVERY frame this receiver was handed since
+    its creation, warm-up and timed frames alike, and compares at every checkpoint: exact arithmetic bit for bit, --fast
+    within 1 LSB int16 / 1e-5 of max|ref| on the final cf32 stream (north_star's tolerance).  sdrj.cpp:288-294."""
+
+    def __init__(self, job, n_random=64, seed=20261002):
+        from sdrreceiver_amd import topology as tp
+        self.job = job
+        self.sample = tp.sample_leaves(job.topo, n_random, seed)
+        self.sub, self.remap = tp.subset(job.topo, self.sample)
+        self.points = []   # (frames handed over so far, {leaf: payload}, {leaf: stream} | None)
+
+    def checkpoint(self, with_streams=False):
+        j = self.job
+        j.rx.set_publish(False)  # (a ctypes callback per leaf costs microseconds: the payloads are read through sdrx_get_output)
+        j.rx.fetch()
+        j.rx.set_publish(True)
+        pay = {i: j.rx.output(i) for i in self.sample}
+        st = {i: j.rx.stream(i, missing_ok=True) for i in self.sample} if with_streams else None
+        self.points.append((len(j.hist), pay, st))
+        j.step(len(j.hist))     # refill the frame pipeline: untimed, and part of the history like every other frame
+        j.realign(len(j.hist))
+
+    def finish(self, exact, rel_tol=1e-5):
+        import numpy as np
+        from oracle import binding as ob
+        j = self.job
+        t0 = time.perf_counter()
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        nodes, roots = ob.build_tree("port", self.sub)
+        done, bad, worst, checked = 0, [], 0.0, 0
+        try:
+            for upto, pay, st in self.points:
+                k = done
+                while k < upto:  # runs of the same frame go through the oracle in one call
+                    e = k
+                    while e < upto and j.hist[e] == j.hist[k]:
+                        e += 1
+                    ob.process_roots(roots, j.frames_np[j.hist[k]], frames=e - k, threads=threads)
+                    k = e
+                done = upto
+                for i in self.sample:
+                    ref = nodes[self.remap[i]]
+                    want = ref.usb() if j.topo.vfos[i].demod_usb else ref.iq()
+                    got = pay[i]
+                    if exact:
+                        ok = np.array_equal(got, want)
+                    else:
+                        ok = got.shape == want.shape and int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max()) <= 1
+                    if ok and st is not None and st[i] is not None:
+                        rs = ref.stream()
+                        if exact:
+                            ok = np.array_equal(st[i].view(np.uint64), rs.view(np.uint64))
+                        else:
+                            err = float(np.abs(st[i] - rs).max()) / max(float(np.abs(rs).max()), 1e-30)
+                            worst = max(worst, err)
+                            ok = err <= rel_tol
+                    checked += 1
+                    if not ok:
+                        bad.append((upto, i))
+        finally:
+            for r in roots:
+                r.free()
+        out = {"ok": not bad, "leaves": len(self.sample), "checkpoints": len(self.points), "frames": done,
+               "compared": "int16 payloads at every checkpoint (after each timed repetition) + final cf32 streams at the last one; "
+                           + ("bit for bit" if exact else f"+-1 LSB / {rel_tol:g} of max|ref|"),
+               "against": "oracle/vfo_oracle.c (plain-C restatement, pinned to the compiled reference) over every frame of the run",
+               "leaf_checks": checked, "oracle_s": round(time.perf_counter() - t0, 1), "oracle_threads": threads}
+        if not exact:
+            out["worst_stream_rel_err"] = float(f"{worst:.3g}")
+        if bad:
+            out["mismatches"] = [{"after_frames": a, "vfo": b} for a, b in bad[:8]]
+        return out
+
+
 def pmc_for(workload, exact):
     """profiles/current_pmc.json (tools/profile.sh + tools/pmc_summary.py): per-launch counter means of
     the committed PMC passes, if they were taken on this workload and arithmetic."""
@@ -251,6 +332,9 @@ def main():
     ap.add_argument("--fast", action="store_true", help="FMA arithmetic (within 1e-6 of the reference) instead of bit-exact")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-abi", action="store_true", help="skip the through-the-ABI (host buffers, PCIe both ways) leg")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the oracle check of the timed launch sequence (`verified` in the line; a profiled command skips it: "
+                         "the checkpoints add fetches and single-level launches to the kernel statistics)")
     ap.add_argument("--no-side", action="store_true",
                     help="skip the side readings of the N = 1 line (north-star 10 240 subs, flat 1 024, config 4): a profiled "
                          "command must launch the kernels of ONE workload only")
@@ -335,6 +419,7 @@ def main():
             self.src = torch.from_numpy(np.concatenate(self.frames_np)).to(dev) if rank == 0 else None
             self.bcast = D.FrameBroadcast(self.frame, dev, src_rank=0, frames_per_batch=batch)
             self.cur = None
+            self.hist = []  # which of the `batch` source frames every step so far was handed (the verifier replays it)
             self.overlap = True
             try:  # the broadcast of batch k+1 (RCCL, its own stream) overlaps the processing of batch k
                 self.bcast.submit(self.src)
@@ -347,6 +432,7 @@ def main():
             j = k % batch
             if j == 0:
                 self.cur = self.bcast.result() if self.overlap else self.bcast(self.src)
+            self.hist.append(j)
             if self.rx:
                 self.rx.process_device(self.cur.data_ptr() + j * self.frame * 8, self.frame)
                 if fetch:
@@ -362,7 +448,7 @@ def main():
             barrier()
             return allmax(time.perf_counter() - t0)
 
-        def measure(self, steps, warmup, reps):
+        def measure(self, steps, warmup, reps, verifier=None):
             for k in range(warmup):
                 self.step(k)
             self.realign(warmup)
@@ -376,6 +462,8 @@ def main():
             for _ in range(reps):
                 out.append(self.timed(steps))
                 self.realign(steps)
+                if verifier:
+                    verifier.checkpoint()  # outside the timed region: payloads of the frame the region ended on
             return out
 
         def realign(self, steps_done):
@@ -426,10 +514,13 @@ def main():
         of the N = 1 line.  `value` and `ms_per_step` of the line stay those of the default workload."""
         try:
             j = Job(name)
-            sreps = j.measure(args.steps, args.warmup, max(1, min(args.reps, 5)))
+            sv = Verifier(j, n_random=32) if (j.rx and not args.no_verify) else None
+            sreps = j.measure(args.steps, args.warmup, max(1, min(args.reps, 5)), sv)
             sdt = statistics.median(sreps)
             ks = min(args.steps, 12)
             skt, skern, sdom, sfk = kernel_pass(j, ks)
+            if sv:
+                sv.checkpoint(with_streams=True)
             fsec = j.full.frame / j.full.fs
             o = {"workload": j.descr, "sub_vfos": int(j.st["n_leaves"]), "ms_per_step": round(sdt / args.steps * 1e3, 4),
                  "ms_per_step_min": round(min(sreps) / args.steps * 1e3, 4), "ms_per_step_max": round(max(sreps) / args.steps * 1e3, 4),
@@ -442,6 +533,11 @@ def main():
                 o["roofline"] = roofline_object(sdom, skt[sdom], ks, sfk, j.st["algorithmic_bytes_per_frame"], 1,
                                                 pmc_for(name, not args.fast), j.st["mix_chunks_per_frame"], demanded_valu_per_launch(j.topo))
             o["kernels"] = {k: v["avg_ms"] for k, v in skern.items()}
+            if sv:
+                try:
+                    o["verified"] = sv.finish(exact=not args.fast)
+                except Exception as e:
+                    o["verified"] = {"ok": None, "error": f"{type(e).__name__}: {e}"}
             j.close()
             return o
         except Exception as e:  # the bench line must still come out
@@ -462,12 +558,25 @@ def main():
 
     job = Job(workload)
     topo, rx, st, full, descr = job.topo, job.rx, job.st, job.full, job.descr
-    reps = job.measure(args.steps, args.warmup, max(1, args.reps))
+    ver = Verifier(job) if (rx and not args.no_verify) else None
+    reps = job.measure(args.steps, args.warmup, max(1, args.reps), ver)
     dt = statistics.median(reps)
     vfo_samples, alg_bytes, n_leaves = allsum([st["vfo_samples_per_frame"], st["algorithmic_bytes_per_frame"], st["n_leaves"]])
 
     kt_steps = min(args.steps, 20)
     kt, kernels, dom, frame_kernel_ms = kernel_pass(job, kt_steps)
+    verified = None
+    if ver:
+        ver.checkpoint(with_streams=True)
+        try:  # (the oracle runs here, on the host, before the legs below put other frames through this receiver)
+            verified = ver.finish(exact=not args.fast)
+        except Exception as e:
+            verified = {"ok": None, "error": f"{type(e).__name__}: {e}"}
+    if use_dist:  # every rank checks its own shard; the line reports the worst
+        nbad = allsum([0.0 if (verified is None or verified.get("ok")) else 1.0])[0]
+        if verified is not None and nbad:
+            verified["ok"] = False
+            verified["ranks_with_mismatches"] = int(nbad)
 
     # third (N = 1): through the C ABI from HOST buffers -- what a Qt / C++ host sees, PCIe both ways.
     abi = None
@@ -586,6 +695,7 @@ def main():
         except Exception as e:
             weak = {"error": f"{type(e).__name__}: {e}"}
 
+    failed = []
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         frame_seconds = full.frame / full.fs
@@ -614,6 +724,8 @@ def main():
             "algorithmic_GBps_whole_frame": round(args.steps * alg_bytes / dt / 1e9, 1),
             "frame_frac_of_hbm_roofline": round(args.steps * alg_bytes / world / dt / 1e9 / HBM_PEAK_GBS, 4),
         }
+        if verified is not None:
+            out["verified"] = verified
         if dom:
             pm = pmc_for(workload, not args.fast)
             out["roofline"] = roofline_object(dom, kt[dom], kt_steps, frame_kernel_ms, alg_bytes, world, pm, st["mix_chunks_per_frame"],
@@ -660,10 +772,15 @@ def main():
             except Exception as e:  # the bench line must still come out
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
+        failed = [k for k, v in [("", out)] + [(k, v) for k, v in out.items() if isinstance(v, dict)]
+                  if isinstance(v.get("verified"), dict) and v["verified"].get("ok") is False]
     if job:
         job.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0 and failed:
+        print(f"bench: the timed launch sequence did NOT reproduce the oracle ({failed})", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

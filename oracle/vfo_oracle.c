@@ -573,21 +573,42 @@ void orc_vfo_process(orc_vfo *v, const float *iq, int n)
  * another VFO's state (vfo.cpp:253-264) -- as the "all host cores" CPU baseline. */
 void orc_process_roots(orc_vfo **roots, int n_roots, const float *iq, int n, int frames, int threads)
 {
+    if (threads <= 1) {
+        for (int f = 0; f < frames; ++f)
+            for (int r = 0; r < n_roots; ++r)
+                orc_vfo_process(roots[r], iq, n);
+        return;
+    }
+    /* VFOs do not see each other (vfo.cpp:253-264: every child is handed the same read-only buffer), so the order the
+     * reference walks them in -- sdrj.cpp:288-294 over the mains, each main over its children -- is free: per frame first
+     * every root (a root with children: its own mix + cascade only), then all children of all roots, both in parallel. */
+    int n_kids = 0;
+    for (int r = 0; r < n_roots; ++r)
+        n_kids += roots[r]->n_children;
+    orc_vfo **kid = (orc_vfo **)malloc(sizeof(orc_vfo *) * (size_t)(n_kids ? n_kids : 1));
+    int *kid_root = (int *)malloc(sizeof(int) * (size_t)(n_kids ? n_kids : 1));
+    for (int r = 0, k = 0; r < n_roots; ++r)
+        for (int a = 0; a < roots[r]->n_children; ++a, ++k) {
+            kid[k] = roots[r]->children[a];
+            kid_root[k] = r;
+        }
     for (int f = 0; f < frames; ++f) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
         for (int r = 0; r < n_roots; ++r) {
             orc_vfo *v = roots[r];
-            if (threads <= 1 || v->n_children == 0) {
+            if (v->n_children == 0)
                 orc_vfo_process(v, iq, n);
-                continue;
-            }
-            mix_and_decimate(v, iq, n < v->samples_per_buffer ? n : v->samples_per_buffer);
-            const float *s = v->stream[v->decimate_count];
-            int sn = v->stream_len[v->decimate_count];
+            else
+                mix_and_decimate(v, iq, n < v->samples_per_buffer ? n : v->samples_per_buffer);
+        }
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-            for (int a = 0; a < v->n_children; ++a)
-                orc_vfo_process(v->children[a], s, sn);
+        for (int k = 0; k < n_kids; ++k) {
+            const orc_vfo *v = roots[kid_root[k]];
+            orc_vfo_process(kid[k], v->stream[v->decimate_count], v->stream_len[v->decimate_count]);
         }
     }
+    free(kid);
+    free(kid_root);
 }
 
 /* ======================================================================= accessors */

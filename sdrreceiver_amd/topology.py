@@ -440,47 +440,41 @@ def shard(topo: Topology, rank: int, world: int) -> Topology:
                     zmq_address=topo.zmq_address, vfos=vfos, name=f"{topo.name}[{rank}/{world}]")
 
 
-# ---- test utility: seeded random trees (tests/test_gpu_parity.py, tools/dropin_run.py random:<seed>) ------------------
-def random_topology(rng) -> Topology:
-    """A random tree inside the library's documented restrictions: 1-3 levels, depths 0-4, frames of
-    16 * 2^k * m samples (last chunk partial), rates 1x-4x the frame, USB leaves with and without the
-    audio low-pass and the /5 or /6 late decimation, IQ leaves with both compress styles."""
-    depth_budget = 7
-    n_root = 16 * (1 << depth_budget) * int(rng.integers(3, 13))  # 6 144 .. 24 576, divisible by 16 * 2^7
-    fs_root = n_root * int(rng.choice([1, 2, 4]))
-    t = Topology(fs=fs_root, frame=n_root, name="rnd")
+def subset(topo: Topology, leaves) -> tuple[Topology, dict[int, int]]:
+    """The VFOs `leaves` (indices into topo.vfos) with every VFO above them as a tree of its own, node order kept; returns
+    it with the map old index -> new index.  A VFO's output depends on its ancestors only -- every child is handed the same
+    read-only buffer (vfo.cpp:253-264) -- so the subset computes exactly what the same VFOs compute inside the full tree
+    (what the sharding above rests on; bench.py and the full-size tests run the oracle on such subsets)."""
+    keep = set()
+    for i in leaves:
+        j = int(i)
+        while j >= 0 and j not in keep:
+            keep.add(j)
+            j = topo.vfos[j].parent
+    order = sorted(keep)
+    remap = {old: new for new, old in enumerate(order)}
+    vfos = [replace(topo.vfos[i], parent=remap.get(topo.vfos[i].parent, -1)) for i in order]
+    return (Topology(fs=topo.fs, frame=topo.frame, bufsplit=topo.bufsplit, center_frequency=topo.center_frequency,
+                     correct_dc=topo.correct_dc, zmq_address=topo.zmq_address, vfos=vfos, name=f"{topo.name}[subset {len(order)}]"),
+            remap)
 
-    def leaf(parent, fs, n, used):
-        d = int(rng.integers(0, min(4, depth_budget - used) + 1))
-        rate, n_out = fs >> d, n >> d
-        usb = rng.random() < 0.75
-        late = 0
-        if usb and rng.random() < 0.3:
-            for L in (5, 6):
-                if n_out % L == 0 and (n_out // L) >= 64 and rate % L == 0:
-                    late = L
-                    break
-        out_rate = rate // late if late else rate
-        bw = int(out_rate / rng.uniform(2.3, 12.0)) if (usb and rng.random() < 0.5) else 0
-        t.vfos.append(VfoDesc(topic=f"L{len(t.vfos):03d}"[:5], parent=parent, fs=fs, decimate_count=d,
-                                 mixer_freq=float(int(rng.integers(-fs // 2 + 1, fs // 2))), demod_usb=usb, late_decimate=late,
-                                 filter_bw=bw, gain=_g(float(rng.uniform(0.01, 0.08))), cstyle=int(rng.integers(0, 2)),
-                                 scalecomp=int(rng.choice([1, 2, 4])), samples_per_buffer=n))
 
-    def inner(parent, fs, n, used, level):
-        d = int(rng.integers(0, 3))
-        t.vfos.append(VfoDesc(parent=parent, fs=fs, decimate_count=d, mixer_freq=float(int(rng.integers(-fs // 2 + 1, fs // 2))),
-                                 demod_usb=False, cstyle=1, samples_per_buffer=n))
-        me = len(t.vfos) - 1
-        for _ in range(int(rng.integers(1, 4))):
-            if level < 2 and rng.random() < 0.3:
-                inner(me, fs >> d, n >> d, used + d, level + 1)
-            else:
-                leaf(me, fs >> d, n >> d, used + d)
-
-    for _ in range(int(rng.integers(1, 4))):
-        if rng.random() < 0.7:
-            inner(-1, fs_root, n_root, 0, 1)
-        else:
-            leaf(-1, fs_root, n_root, 0)
-    return t
+def sample_leaves(topo: Topology, n_random: int, seed: int, world: int = 8) -> list[int]:
+    """A seeded choice of publishing leaves for a parity check at sizes the CPU oracle cannot cover whole: for every group
+    of siblings the first and the last leaf of each of the `world` blocks `shard` would make (where an off-by-one of a work
+    list or of the partition shows first) plus `n_random` leaves drawn over all groups."""
+    rng = np.random.default_rng(seed)
+    cm = topo._child_map()
+    groups = [[i for i in ch if i not in cm] for ch in cm.values()]
+    groups = [g for g in groups if g]
+    picked: set[int] = set()
+    for g in groups:
+        for r in range(world):
+            lo, hi = (len(g) * r) // world, (len(g) * (r + 1)) // world
+            if hi > lo:
+                picked.update((g[lo], g[hi - 1]))
+    total = sum(len(g) for g in groups)
+    for g in groups:
+        k = min(len(g), max(1, round(n_random * len(g) / max(total, 1))))
+        picked.update(int(x) for x in rng.choice(g, size=k, replace=False))
+    return sorted(picked)

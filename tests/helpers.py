@@ -103,3 +103,50 @@ def check_against_ofast_fixture(g, topo, f, stream_of, payload_of, o2_payload_of
             patched += idx.size
             total += got.size
     return worst, patched, total
+
+
+# ---- seeded random trees (tests/test_gpu_parity.py, tests/test_dropin_qt.py, tools/dropin_run.py random:<seed>) ----------
+def random_topology(rng):
+    """A random tree inside the library's documented restrictions: 1-3 levels, depths 0-4, frames of
+    16 * 2^k * m samples (last chunk partial), rates 1x-4x the frame, USB leaves with and without the
+    audio low-pass and the /5 or /6 late decimation, IQ leaves with both compress styles."""
+    from sdrreceiver_amd.topology import Topology, VfoDesc, _g
+    depth_budget = 7
+    n_root = 16 * (1 << depth_budget) * int(rng.integers(3, 13))  # 6 144 .. 24 576, divisible by 16 * 2^7
+    fs_root = n_root * int(rng.choice([1, 2, 4]))
+    t = Topology(fs=fs_root, frame=n_root, name="rnd")
+
+    def leaf(parent, fs, n, used):
+        d = int(rng.integers(0, min(4, depth_budget - used) + 1))
+        rate, n_out = fs >> d, n >> d
+        usb = rng.random() < 0.75
+        late = 0
+        if usb and rng.random() < 0.3:
+            for L in (5, 6):
+                if n_out % L == 0 and (n_out // L) >= 64 and rate % L == 0:
+                    late = L
+                    break
+        out_rate = rate // late if late else rate
+        bw = int(out_rate / rng.uniform(2.3, 12.0)) if (usb and rng.random() < 0.5) else 0
+        t.vfos.append(VfoDesc(topic=f"L{len(t.vfos):03d}"[:5], parent=parent, fs=fs, decimate_count=d,
+                                 mixer_freq=float(int(rng.integers(-fs // 2 + 1, fs // 2))), demod_usb=usb, late_decimate=late,
+                                 filter_bw=bw, gain=_g(float(rng.uniform(0.01, 0.08))), cstyle=int(rng.integers(0, 2)),
+                                 scalecomp=int(rng.choice([1, 2, 4])), samples_per_buffer=n))
+
+    def inner(parent, fs, n, used, level):
+        d = int(rng.integers(0, 3))
+        t.vfos.append(VfoDesc(parent=parent, fs=fs, decimate_count=d, mixer_freq=float(int(rng.integers(-fs // 2 + 1, fs // 2))),
+                                 demod_usb=False, cstyle=1, samples_per_buffer=n))
+        me = len(t.vfos) - 1
+        for _ in range(int(rng.integers(1, 4))):
+            if level < 2 and rng.random() < 0.3:
+                inner(me, fs >> d, n >> d, used + d, level + 1)
+            else:
+                leaf(me, fs >> d, n >> d, used + d)
+
+    for _ in range(int(rng.integers(1, 4))):
+        if rng.random() < 0.7:
+            inner(-1, fs_root, n_root, 0, 1)
+        else:
+            leaf(-1, fs_root, n_root, 0)
+    return t

@@ -174,11 +174,11 @@ def test_adapter_on_random_trees():
         pytest.skip("oracle/_ref/libdropin_ref.so not built (make -C host/qt needs /root/reference)")
     import numpy as np
     sys.path.insert(0, ROOT)
-    from sdrreceiver_amd import topology as tp
+    from helpers import random_topology
     n = max(3, int(os.environ.get("SDRX_TEST_SEEDS", "60")) // 20)
     ran = 0
     for seed in range(n):
-        topo = tp.random_topology(np.random.default_rng(1000 + seed))
+        topo = random_topology(np.random.default_rng(1000 + seed))
         if any(v.fs < 1024 or 0 < v.samples_per_buffer % 1024 < 256 for v in topo.vfos):
             continue
         fft = next((v.topic for v in reversed(topo.vfos) if v.topic), "")

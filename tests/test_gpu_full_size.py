@@ -106,21 +106,47 @@ def _frames(topo, n, seed=1):
             for f in range(n)]
 
 
-def _every_sub_vfo_against_the_oracle(topo, n_frames):
+def _every_sub_vfo_against_the_oracle(topo, n_frames, queued=False, **options):
     """Payload (int16 audio as published) and final cf32 stream of EVERY sub VFO of `topo`, `n_frames` frames, against
     the plain-C oracle.  The oracle keeps a whole NCO table per VFO (oscillator.cpp:13-30: 1.5-3 MB each), so it runs
     the tree in batches of 1 024 sub VFOs on all host cores -- legal because a VFO's output does not depend on its
-    siblings (vfo.cpp:253-264).  The GPU side is kept as one sha256 per VFO, frame and kind."""
+    siblings (vfo.cpp:253-264).  The GPU side is kept as one sha256 per VFO, frame and kind.
+
+    `queued`: the launch sequence bench.py times -- every frame handed over with sdrx_process_device on a torch stream,
+    back to back with no synchronisation in between (ONE k_mix_levels launch per call, level l on frame k - l, the leaf
+    tail of the frame that left the last level behind it), ONE sdrx_fetch at the end: the LAST frame's payloads and
+    streams are what can be read then, and they are compared (they carry every earlier frame in their NCO phase and
+    filter histories)."""
     import os
     from sdrreceiver_amd.receiver import Receiver
     frames = _frames(topo, n_frames)
-    rx = Receiver.from_topology(topo)
+    rx = Receiver.from_topology(topo, **options)
     subs = [i for i in range(len(topo.vfos)) if topo.vfos[i].parent >= 0]
-    got = []
-    for iq in frames:
-        rx.process(iq)
+
+    def digests():
+        out = {}
+        for i in subs:
+            z = rx.stream(i, missing_ok=True)  # (None: a fused late decimation keeps no decimate[0]; its payload is checked)
+            out[i] = (hashlib.sha256(rx.output(i).tobytes()).digest(), None if z is None else hashlib.sha256(z.tobytes()).digest())
+        return out
+
+    got = {}
+    if queued:
+        import torch
+        st = torch.cuda.Stream()
+        rx.set_stream(st.cuda_stream)
+        with torch.cuda.stream(st):
+            dev = [torch.from_numpy(iq).cuda(non_blocking=True) for iq in frames]
+            for d in dev:
+                rx.process_device(d.data_ptr(), topo.frame)
+        rx.fetch()
         assert len(rx.published) == len(subs)
-        got.append({i: (hashlib.sha256(rx.output(i).tobytes()).digest(), hashlib.sha256(rx.stream(i).tobytes()).digest()) for i in subs})
+        got[n_frames - 1] = digests()
+    else:
+        for f, iq in enumerate(frames):
+            rx.process(iq)
+            assert len(rx.published) == len(subs)
+            got[f] = digests()
     rx.close()
     threads = max(1, len(os.sched_getaffinity(0)))
     checked = 0
@@ -129,13 +155,27 @@ def _every_sub_vfo_against_the_oracle(topo, n_frames):
         onodes, oroots = _oracle_subset(topo, batch)
         for f, iq in enumerate(frames):
             ob.process_roots(oroots, iq, threads=threads)
+            if f not in got:
+                continue
             for k, i in enumerate(batch):
                 assert hashlib.sha256(onodes[k].usb().tobytes()).digest() == got[f][i][0], (f, i, "payload")
-                assert hashlib.sha256(onodes[k].stream().tobytes()).digest() == got[f][i][1], (f, i, "stream")
+                assert got[f][i][1] is None or hashlib.sha256(onodes[k].stream().tobytes()).digest() == got[f][i][1], (f, i, "stream")
                 checked += 1
         for r in oroots:
             r.free()
     return checked
+
+
+@pytest.mark.parametrize("workload", ["config3-1024", "north-star-10240", "config4-256"])
+def test_every_sub_vfo_in_the_queued_form_bench_times(workload):
+    """What bench.py's timed region launches, at the sizes it is quoted on, with the oracle on EVERY sub VFO: 8 frames queued
+    with sdrx_process_device on a torch stream (k_mix_levels with the software pipeline over frames: level l works on
+    frame k - l), one fetch, payloads and final cf32 streams of the last frame bit-identical to the plain-C oracle.
+    BASELINE config 3 (1 024 sub VFOs), the north-star size (10 240) and config 4 (256 fused /5 leaves, whose payloads
+    are compared: they keep no decimate[0]).  sdrj.cpp:288-294 -> vfo.cpp:235-296."""
+    topo = {"config3-1024": lambda: tp.config3(1024), "north-star-10240": lambda: tp.config3(10240), "config4-256": lambda: tp.config4(256)}[workload]()
+    n_subs = sum(1 for v in topo.vfos if v.parent >= 0)
+    assert _every_sub_vfo_against_the_oracle(topo, 8, queued=True) == n_subs
 
 
 def test_all_10240_vfos_of_the_north_star_workload_bit_exact():

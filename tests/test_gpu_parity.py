@@ -10,7 +10,7 @@ pre-quantisation float ``usb*gain*32768``, int16 within +-1 LSB.  The library's 
 import numpy as np
 import pytest
 
-from helpers import GOLDEN_TREES, bits, golden, golden_topology, sha
+from helpers import GOLDEN_TREES, bits, golden, golden_topology, random_topology, sha
 from oracle import binding as ob
 from sdrreceiver_amd import synth, topology as tp
 
@@ -860,7 +860,7 @@ def test_all_decimation_depths_and_tiny_frames(Receiver, segments):
 
 
 def _random_topology(rng):
-    return tp.random_topology(rng)
+    return random_topology(rng)
 
 
 N_SEEDS = int(__import__("os").environ.get("SDRX_TEST_SEEDS", "60"))  # (a one-off soak run: SDRX_TEST_SEEDS=600)

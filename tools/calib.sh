@@ -20,7 +20,7 @@ i=0
 for S in "$SETA" "$SETB"; do
   i=$((i+1))
   rocprofv3 --pmc $S -d "$OUT" -o probe$i --output-format csv -- ./tools/valu_calib 5 3000 > "$OUT/probe$i.jsonl" 2> "$OUT/probe$i.err" || echo "probe pass $i failed" >> "$OUT/errors.txt"
-  rocprofv3 --pmc $S -d "$OUT" -o bench$i --output-format csv -- python3 bench.py --steps 6 --warmup 2 --reps 3 --no-cpu --no-abi --no-side > "$OUT/bench$i.json" 2> "$OUT/bench$i.err" || echo "bench pass $i failed" >> "$OUT/errors.txt"
+  rocprofv3 --pmc $S -d "$OUT" -o bench$i --output-format csv -- python3 bench.py --steps 6 --warmup 2 --reps 3 --no-cpu --no-abi --no-side --no-verify > "$OUT/bench$i.json" 2> "$OUT/bench$i.err" || echo "bench pass $i failed" >> "$OUT/errors.txt"
   rocprofv3 --pmc $S -d "$OUT" -o tenk$i --output-format csv -- python3 bench.py --workload 10k --steps 6 --warmup 2 --reps 3 --no-cpu --no-abi > "$OUT/tenk$i.json" 2> "$OUT/tenk$i.err" || echo "10k pass $i failed" >> "$OUT/errors.txt"
 done
 ls "$OUT" | tr '\n' ' '

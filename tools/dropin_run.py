@@ -36,7 +36,9 @@ def topology(name):
         return tp.config4(12)
     if name.startswith("random:"):  # the seeded random trees of tests/test_gpu_parity.py
         import numpy as np
-        return tp.random_topology(np.random.default_rng(1000 + int(name.split(":")[1])))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import random_topology  # test infrastructure: the generator lives with the tests
+        return random_topology(np.random.default_rng(1000 + int(name.split(":")[1])))
     raise SystemExit(f"unknown topology {name}")
 
 

@@ -3,7 +3,7 @@
 TAG=$1; PMC=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmcq_$TAG; mkdir -p $OUT
-rocprofv3 --pmc $PMC -d $OUT -o p --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu --no-abi --no-side $* > $OUT/bench.json 2> $OUT/err.txt
+rocprofv3 --pmc $PMC -d $OUT -o p --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu --no-abi --no-side --no-verify $* > $OUT/bench.json 2> $OUT/err.txt
 python3 - <<PY
 import csv, collections, glob
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
