@@ -83,9 +83,13 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
 /* Options, all before sdrx_finalize:
  *   "exact"  1 (default): every fp32 operation rounded like the reference's -O2 x86-64 build
  *            (no FMA contraction, reference summation order) -> results bit-identical to it.
- *            0: an A/B SWITCH, not a feature: the filters' multiply-adds as FMAs (within 1e-6 relative of the
- *            reference, int16 within 1 LSB).  It buys ~5 % on this hardware -- a packed or paired mul + add issues
- *            as fast as an FMA here (profiles/README.md) -- and is kept so that the cost of exactness stays measurable.
+ *            0: the TOLERANCE arithmetic -- what BASELINE.json's north_star grants ("within 1e-5 relative float
+ *            tolerance"): every final complex stream and pre-quantisation float within 1e-5 of max|reference| per
+ *            VFO-frame, int16 within 1 LSB (tests: every VFO of configs 3 / 4 and of the 10 240-VFO workload, 18 s runs
+ *            without drift, the -Ofast build's fixtures).  The NCO table entries (oscillator.cpp:20-28) become rotations
+ *            of the table's EXACT 16-entry checkpoints (<= 1e-6 from the table, never accumulating; the table's first 512
+ *            entries and the first sample ever are still replayed exactly), the mixer (vfo.cpp:241) a packed multiply +
+ *            FMA, the half-band / FIR dot products FMAs: ~230 instead of ~390 vector instructions per 1024 samples.
  *   "keep_prequant" 1: also keep the pre-quantisation float `usb*gain*32768` per leaf
  *            (parity tests; sdrx_get_prequant).   default 0
  *   "segments" n: force n time-segments per VFO-frame in the decimation kernel (0 = auto).

@@ -205,6 +205,52 @@ __device__ __forceinline__ v2f nco_step_pk(v2f v, v2f rot)
     return n * norm;
 }
 
+// NCO in the tolerance arithmetic (option exact = 0; north_star: "within 1e-5 relative float tolerance").  Once the table's
+// amplitude has settled (the stabiliser 1.95f - |v|^2 pulls |v|^2 to 0.95 with the factor -0.9 per step: ~150 entries,
+// oscillator.cpp:20-28) a step of the recurrence is a rotation by arg(rot) at constant modulus, plus its own rounding noise.
+// So from the EXACT checkpoint c = table[16 j - 1] the 16 entries behind it are rotations of it:  with rk[q] = u^(q+1),
+// q = 0..3, computed in double at finalize,  table[b + q] = base * rk[q]  for base = c, then table[b + 3] of the block
+// before (four blocks of four; an entry is at most four products away from the checkpoint) -- two-instruction products
+// with four wave-uniform constants instead of a 16-deep chain of seven instructions.  Measured against the reference's
+// tables (the (Fs, f) pairs of the shipped profiles): max 1.0e-6, rms 2e-7 relative on entries >= 512; a checkpoint is
+// never more than 16 entries away, so nothing accumulates over a frame or a run.  Chunks that touch the first kNcoSettle
+// entries of the table (start-up ringing; the very first sample's table[L-1]) replay it exactly.
+//
+// Two samples per statement:  m_k = base * r_k  (the table entries; r_k wave-uniform, an SGPR pair),  x_k = m_k * x_k  (the
+// mixer, vfo.cpp:241).  A complex product (a.x b.x - a.y b.y, a.x b.y + a.y b.x) is ONE packed multiply (a.x, a.x) * b and
+// ONE packed FMA (a.y, a.y) * (-b.y, b.x) + that: the broadcast of a's halves, the swap of b's and the sign are source
+// modifiers (op_sel, op_sel_hi, neg_lo) -- written out because the compiler finds them for one product in eight and
+// builds (-b.y, b.x) with a v_xor and a v_mov for the others.  The two samples' instructions alternate, so none reads the
+// result of the one before it (gfx950 wants one wait state behind a packed fp32 instruction; nobody inserts it inside an
+// asm statement).  Returns m_1 (the later entry: the next block's base).
+__device__ __forceinline__ v2f nco_mix_fast2(v2f base, v2f r0, v2f r1, v2f &x0, v2f &x1)
+{
+    v2f m0, m1, y0, y1; // (results in registers of their own: written in place, the compiler copies the inputs first)
+    asm("v_pk_mul_f32 %2, %6, %7 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %6, %8 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %2, %6, %7, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %3, %6, %8, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_mul_f32 %0, %2, %4 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %3, %5 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(y0), "=&v"(y1), "=&v"(m0), "=&v"(m1)
+        : "v"(x0), "v"(x1), "v"(base), "s"(r0), "s"(r1));
+    x0 = y0, x1 = y1;
+    return m1;
+}
+// the 16 entries behind checkpoint `c` and the mixer on the lane's 16 samples
+__device__ __forceinline__ void nco_mix_fast16(v2f c, const float2 *__restrict__ rk, v2f *x)
+{
+    const v2f r0 = {ldc(&rk[0].x), ldc(&rk[0].y)}, r1 = {ldc(&rk[1].x), ldc(&rk[1].y)};
+    const v2f r2 = {ldc(&rk[2].x), ldc(&rk[2].y)}, r3 = {ldc(&rk[3].x), ldc(&rk[3].y)};
+#pragma unroll
+    for (int b = 0; b < kRun; b += 4) {
+        nco_mix_fast2(c, r0, r1, x[b], x[b + 1]);
+        c = nco_mix_fast2(c, r2, r3, x[b + 2], x[b + 3]);
+    }
+}
+
 // Replays the whole table once per VFO and keeps every 16th entry: cp[j] = table[16j-1]
 // (cp[0] = the initial (1,0)), so any aligned run of 16 entries can be regenerated in
 // registers, bit-exact by construction.  One thread per VFO; init-time only.
@@ -828,13 +874,23 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         idx -= idx >= D.L ? D.L : 0;
         v2f o = gldv2(D.cp + (idx >> 4));
         const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
+        bool replay = true;
+        if constexpr (!EXACT) { // (wave-uniform) the chunk's 1024 table entries are settled ones and do not wrap
+            int i0 = phase_frame + base;
+            i0 -= i0 >= D.L ? D.L : 0;
+            replay = i0 < kNcoSettle || i0 + kChunk > D.L;
+        }
+        if (replay) {
 #pragma unroll
-        for (int i = 0; i < kRun; ++i) {
-            o = nco_step_pk(o, rot);
-            v2f m = o;
-            if (i == 0 && first_ever)
-                m = gldv2(D.cp + (D.L >> 4));
-            x[i] = cmul(m, x[i]);
+            for (int i = 0; i < kRun; ++i) {
+                o = nco_step_pk(o, rot);
+                v2f m = o;
+                if (i == 0 && first_ever)
+                    m = gldv2(D.cp + (D.L >> 4));
+                x[i] = cmul(m, x[i]);
+            }
+        } else {
+            nco_mix_fast16(o, Dp->rk, x);
         }
 
         if (D.d == 0) {
@@ -1073,13 +1129,23 @@ __device__ __forceinline__ void late_item(const K1Vfo *__restrict__ vfos, const 
         idx -= idx >= D.L ? D.L : 0;
         v2f o = gldv2(D.cp + (idx >> 4));
         const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
+        bool replay = true;
+        if constexpr (!EXACT) { // (wave-uniform) settled table entries, no wrap inside the chunk: the tolerance arithmetic's NCO
+            int i0 = phase_frame + base;
+            i0 -= i0 >= D.L ? D.L : 0;
+            replay = i0 < kNcoSettle || i0 + kChunk > D.L; // (the lanes past the chunk replay entries nobody uses: up to 64 x 16)
+        }
+        if (replay) {
 #pragma unroll
-        for (int i = 0; i < kRun; ++i) {
-            o = nco_step_pk(o, rot);
-            v2f m = o;
-            if (i == 0 && first_ever)
-                m = gldv2(D.cp + (D.L >> 4));
-            x[i] = cmul(m, x[i]);
+            for (int i = 0; i < kRun; ++i) {
+                o = nco_step_pk(o, rot);
+                v2f m = o;
+                if (i == 0 && first_ever)
+                    m = gldv2(D.cp + (D.L >> 4));
+                x[i] = cmul(m, x[i]);
+            }
+        } else {
+            nco_mix_fast16(o, Dp->rk, x);
         }
         if (tap && lane < G::kMixLanes && 16 * lane < valid && base + 16 * lane >= W.s_first_out) {
             // decimate[0] is wanted (the GUI's spectrum tap, parity tests)
@@ -1163,7 +1229,9 @@ __device__ __forceinline__ void late_item(const K1Vfo *__restrict__ vfos, const 
         wave_sync();
         if (base + valid == D.n_in) {
             // the frame's last kHc mixed samples are the next frame's history (sample valid - kHc + t of this chunk)
-            for (int t = lane; t < kHc; t += 64) {
+            int lane_here = lane; // (the per-lane address is computed HERE: hoisted above the chunk loop it is one live 64-bit value too many)
+            asm volatile("" : "+v"(lane_here));
+            for (int t = lane_here; t < kHc; t += 64) {
                 const int pp = valid + t;
                 gstv2(hist_save + t, buf[(pp / kRow) * kStride + pp % kRow]);
             }

@@ -1268,6 +1268,13 @@ int allocate_and_upload(sdrx_ctx *c, Built &B)
         k.cp = reinterpret_cast<const float2 *>(P(n.off_cp));
         k.rot_re = n.rot_re;
         k.rot_im = n.rot_im;
+        {
+            // the tolerance arithmetic's NCO: 1 .. 4 steps of the recurrence as ONE rotation (the stabiliser holds |v|, so a
+            // step is the rotation by arg(rot) at unit modulus: oscillator.cpp:20-28), in double, stored as floats
+            const double ang = std::atan2((double)n.rot_im, (double)n.rot_re);
+            for (int t = 0; t < 4; ++t)
+                k.rk[t] = make_float2((float)std::cos(ang * (t + 1)), (float)std::sin(ang * (t + 1)));
+        }
         k.n_in = n.d.samples_per_buffer;
         k.d = n.d.decimate_count;
         k.L = n.d.fs;

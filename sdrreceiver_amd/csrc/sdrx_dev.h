@@ -39,7 +39,13 @@ struct K1Vfo {
     int pad_;
     const float *late_taps; // the Nd = LateGeom<L>::kTaps taps of the decimating low-pass
     float2 *tap[2];        // non-null: also keep decimate[0] of this frame here, natural order (sdrx_set_tap, option keep_streams)
+    // Tolerance arithmetic only (option exact = 0; kernels.hip "NCO in the tolerance arithmetic"): rk[j] = u^(j+1), u = the
+    // rotation by the angle of (rot_re, rot_im) at unit modulus, computed in double and stored as floats -- 1 .. 4 steps of
+    // the table's recurrence as one rotation, once its amplitude has settled (entries >= kNcoSettle).
+    float2 rk[4];
 };
+static_assert(sizeof(K1Vfo) % 8 == 0, "K1Vfo array stride");
+constexpr int kNcoSettle = 512; // table entries below this still carry the start-up ringing of the amplitude stabiliser (oscillator.cpp:20-28): always replayed exactly
 
 // Geometry of the fused late decimation for L in {5, 6}.  The decimating low-pass is low_pass(2, rate L, rate / 2, rate / (L - 1))
 // (vfo.cpp:82-87): its length (int)(53 fs / (22 tw)) made odd depends on fs / tw = L (L - 1) only -- 49 taps for L = 5, 73 for

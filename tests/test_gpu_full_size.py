@@ -178,6 +178,71 @@ def test_every_sub_vfo_in_the_queued_form_bench_times(workload):
     assert _every_sub_vfo_against_the_oracle(topo, 8, queued=True) == n_subs
 
 
+REL_TOL = 1e-5  # BASELINE.json north_star: "within 1e-5 relative float tolerance" (of max|ref| per VFO-frame)
+
+
+def _every_sub_vfo_within_tolerance(topo, n_frames):
+    """The TOLERANCE arithmetic (option exact = 0: the table NCO as rotations of its exact checkpoints, the mixer and the
+    filters as FMAs) on EVERY sub VFO of `topo`, in the launch form bench.py times (frames queued with
+    sdrx_process_device, one fetch): final cf32 stream and pre-quantisation float `usb * gain * 32768` within 1e-5 of
+    max|ref|, int16 audio within +-1 LSB of the -O2 oracle's (SURVEY.md 8d's parity criterion).  Returns the worst
+    relative errors seen (stream, pre-quantisation) and the share of int16 samples that differ at all."""
+    import os
+    import torch
+    from sdrreceiver_amd.receiver import Receiver
+    frames = _frames(topo, n_frames)
+    rx = Receiver.from_topology(topo, exact=False, keep_prequant=True)
+    subs = [i for i in range(len(topo.vfos)) if topo.vfos[i].parent >= 0]
+    st = torch.cuda.Stream()
+    rx.set_stream(st.cuda_stream)
+    with torch.cuda.stream(st):
+        dev = [torch.from_numpy(iq).cuda(non_blocking=True) for iq in frames]
+        for d in dev:
+            rx.process_device(d.data_ptr(), topo.frame)
+    rx.fetch()
+    assert len(rx.published) == len(subs)
+    got = {i: (rx.output(i), rx.stream(i, missing_ok=True), rx.prequant(i)) for i in subs}
+    rx.close()
+    threads = max(1, len(os.sched_getaffinity(0)))
+    worst_s = worst_p = 0.0
+    differing = total = 0
+    for b in range(0, len(subs), 1024):
+        batch = subs[b:b + 1024]
+        onodes, oroots = _oracle_subset(topo, batch)
+        for iq in frames:
+            ob.process_roots(oroots, iq, threads=threads)
+        for k, i in enumerate(batch):
+            pay, z, pre = got[i]
+            if z is not None:
+                ref = onodes[k].stream()
+                e = float(np.abs(z - ref).max()) / float(np.abs(ref).max())
+                assert e <= REL_TOL, (i, "stream", e)
+                worst_s = max(worst_s, e)
+            pref = onodes[k].usb_prequant()
+            e = float(np.abs(pre.astype(np.float64) - pref).max()) / float(np.abs(pref).max())
+            assert e <= REL_TOL, (i, "pre-quantisation", e)
+            worst_p = max(worst_p, e)
+            d = np.abs(pay.astype(np.int32) - onodes[k].usb().astype(np.int32))
+            assert d.max() <= 1, (i, "int16 beyond 1 LSB")
+            differing += int(np.count_nonzero(d))
+            total += d.size
+        for r in oroots:
+            r.free()
+    return worst_s, worst_p, differing / total
+
+
+@pytest.mark.parametrize("workload", ["config3-1024", "north-star-10240", "config4-256"])
+def test_every_sub_vfo_in_the_tolerance_arithmetic(workload):
+    """north_star's bar ("audio output within 1e-5 of CPU reference") for the arithmetic that spends it: every sub VFO of
+    BASELINE config 3, of the 10 240-sub north-star workload and of config 4, 8 queued frames (two wraps of the 384 k
+    NCO tables, four of the 192 k ones, one of the 240 k ones with its replayed start-up entries), against the plain-C
+    oracle.  oscillator.cpp:4-50, vfo.cpp:237-245."""
+    topo = {"config3-1024": lambda: tp.config3(1024), "north-star-10240": lambda: tp.config3(10240), "config4-256": lambda: tp.config4(256)}[workload]()
+    ws, wp, frac = _every_sub_vfo_within_tolerance(topo, 8)
+    print(f"{workload}: worst stream error {ws:.3g}, worst pre-quantisation error {wp:.3g} (of max|ref|); {frac:.3%} of the int16 samples differ by 1 LSB")
+    assert ws < REL_TOL and wp < REL_TOL
+
+
 def test_all_10240_vfos_of_the_north_star_workload_bit_exact():
     """BASELINE.json's north-star size with the oracle on EVERY sub VFO, not a sample: 10 240 sub VFOs under the two
     sdr_25E mains, 2 frames; payloads and final cf32 streams bit-identical to the plain-C oracle."""

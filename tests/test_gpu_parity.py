@@ -1208,6 +1208,30 @@ def test_long_run_wraps_the_nco_tables_many_times(Receiver):
     rx.close()
 
 
+def test_tolerance_arithmetic_does_not_drift_over_a_long_run(Receiver):
+    """The tolerance arithmetic rebuilds every run of 16 NCO table entries from an EXACT checkpoint, so its error cannot
+    grow with time: 72 frames = 18 s of signal through the sdr_25E tree (the 1.536 M tables wrap 18 times, the 384 k /
+    192 k ones 18 times, start-up entries replayed at every wrap), checked every 8th frame -- streams and pre-quantisation
+    floats within 1e-5 of max|ref|, int16 within 1 LSB -- and the error at the end no larger than 4x the error after
+    the first second."""
+    topo = golden_topology("profile_25e")
+    rx = Receiver.from_topology(topo, exact=False, keep_prequant=True)
+    nodes, roots = ob.build_tree("port", topo)
+    seen = []
+    for f, iq in _frames(topo, 72, seed=77, tones=[(485000.0, 40.0), (-520000.0, 15.0)]):
+        rx.process(iq)
+        ob.process_roots(roots, iq)
+        if f % 8 == 7:
+            _check_tolerance(rx, nodes, topo, ("no drift", f))
+            e = 0.0
+            for i, v in enumerate(topo.vfos):
+                ref = nodes[i].stream()
+                e = max(e, float(np.abs(rx.stream(i) - ref).max()) / float(np.abs(ref).max()))
+            seen.append(e)
+    rx.close()
+    assert seen[-1] <= 4 * max(seen[0], 1e-7), seen
+
+
 def test_long_queue_of_frames_through_the_pipeline(Receiver):
     """64 frames = 16 s of signal queued back to back with sdrx_process_device on the sdr_25E tree (the
     software pipeline of k_mix_levels stays full for the whole run, every ping-pong buffer flips 64 times,

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""tools/dc_overlap_probe.py [sync|pipelined|both] [frames] -- dongle bytes with the exact DC-bias removal (sdrj.cpp:271-286)
+through config 3, frame after frame: ms per frame, and the event-timed ingest group (k_dc_products + k_dc_chain +
+k_dc_apply) per frame, synchronous (sdrx_process_u8) and pipelined (sdrx_submit_u8 / sdrx_wait).  Run it under
+`rocprofv3 --kernel-trace --stats` for k_dc_chain's own duration in each mode."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+from sdrreceiver_amd import synth, topology as tp  # noqa: E402
+from sdrreceiver_amd.receiver import Receiver  # noqa: E402
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "both"
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+topo = tp.config3(1024)
+u8 = (synth.lcg_frame(topo.frame, synth.Lcg(1)) + 127).astype(np.uint8)
+out = {}
+for m in (["sync", "pipelined"] if mode == "both" else [mode]):
+    rx = Receiver.from_topology(topo)
+    rx.set_publish(False)
+    for _ in range(4):
+        rx.process_u8(u8, correct_dc=True)
+    rx.enable_kernel_timing(True)
+    t0 = time.perf_counter()
+    if m == "sync":
+        for _ in range(frames):
+            rx.process_u8(u8, correct_dc=True)
+    else:
+        rx.submit_u8(u8, correct_dc=True)
+        for _ in range(1, frames):
+            rx.submit_u8(u8, correct_dc=True)
+            rx.wait()
+        rx.wait()
+    dt = (time.perf_counter() - t0) / frames
+    kt = rx.kernel_times()
+    out[m] = {"ms_per_frame": round(dt * 1e3, 4), "kernels_ms_per_launch": {k: round(v["ms"] / v["launches"], 4) for k, v in kt.items()}}
+    rx.close()
+print(json.dumps(out))
