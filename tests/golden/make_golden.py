@@ -191,6 +191,60 @@ def gen_ofast():
         print(f"ofast_{key}.npz: {ndiff} of {total} int16 samples differ from the -O2 build")
 
 
+CAPTURE_FRAMES = 8  # 2 s of signal at 1.536 MS/s
+
+
+def gen_capture():
+    """Row "recorded IQ" (BASELINE.json north_star; SURVEY.md 8c: the reference holds no recording): the capture-like byte
+    stream of sdrreceiver_amd/synth.py (capture_like_u8: tuner noise, strong carriers past +-100, an ADC offset, 600 / 1200 Bd
+    BPSK and 10 500 Bd OQPSK bursts on sdr_25E VFO frequencies) through the shipped sdr_25E profile as the reference runs
+    it: bytes -> b - 127 (jonti/sdr.cpp:43-49) -> DC-bias removal (sdrj.cpp:271-286, correct_dc_bias=1; restated in
+    oracle/vfo_oracle.c -- sdrj.cpp itself cannot be compiled here) -> the REAL reference's vfo tree, -O2 and, as a
+    patch against it, the -Ofast build the project ships.  Per VFO and frame: sha256 + head + max|z| of the final complex
+    stream, sha256 + head of the int16 payload; for -Ofast the stream's every 128th sample and the payload patch."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    topo = tp.profile_25e()
+    u8 = synth.capture_like_u8(CAPTURE_FRAMES, topo.frame, topo.fs)
+    d = {"frames": np.int64(CAPTURE_FRAMES), "input_sha256": np.array(hashlib.sha256(u8.tobytes()).hexdigest())}
+    ref = ob.build_tree("reference", topo)
+    fast = ob.build_tree("reference_ofast", topo) if ob.have_reference_ofast() else None
+    state = np.zeros(2, np.float32)
+    ndiff = total = 0
+    peak = 0
+    for f in range(CAPTURE_FRAMES):
+        iq = ob.u8_to_float(u8[2 * topo.frame * f: 2 * topo.frame * (f + 1)])
+        ob.dc_correct(iq, state)
+        d[f"f{f}_dc_state"] = state.copy()
+        d[f"f{f}_raw_sha"] = np.array(sha(iq))
+        ob.process_roots(ref[1], iq)
+        if fast:
+            ob.process_roots(fast[1], iq)
+        for i, v in enumerate(topo.vfos):
+            z = ref[0][i].stream()
+            d[f"f{f}_v{i}_stream_sha"] = np.array(sha(z))
+            d[f"f{f}_v{i}_stream_head"] = z[:64].copy()
+            d[f"f{f}_v{i}_stream_absmax"] = np.float32(np.abs(z).max())
+            if not topo.children(i):
+                a = ref[0][i].usb()
+                peak = max(peak, int(np.abs(a.astype(np.int32)).max()))
+                d[f"f{f}_v{i}_pay_sha"] = np.array(sha(a))
+                d[f"f{f}_v{i}_pay_head"] = a[:64].copy()
+                if fast:
+                    b = fast[0][i].usb()
+                    idx = np.flatnonzero(a != b).astype(np.int32)
+                    d[f"f{f}_v{i}_ofast_pay_idx"] = idx
+                    d[f"f{f}_v{i}_ofast_pay_val"] = b[idx].copy()
+                    d[f"f{f}_v{i}_ofast_pay_sha"] = np.array(sha(b))
+                    ndiff += idx.size
+                    total += a.size
+            if fast:
+                zf = fast[0][i].stream()
+                d[f"f{f}_v{i}_ofast_stream_every128"] = zf[::128].copy()
+                d[f"f{f}_v{i}_ofast_stream_absmax"] = np.float32(np.abs(zf).max())
+    np.savez_compressed(os.path.join(OUT, "capture_25e.npz"), **d)
+    print(f"capture_25e.npz: {CAPTURE_FRAMES} frames, int16 peak {peak}; -Ofast: {ndiff} of {total} int16 samples differ from the -O2 build")
+
+
 def gen_zmq():
     """ZmqPublisher::publish framing through the real libzmq (ipc transport)."""
     import ctypes as C
@@ -235,6 +289,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dropin":
         gen_dropin()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "capture":
+        if not ob.have_reference():
+            sys.exit("oracle/_ref/libsdrref.so missing: run `make -C oracle/ref` first (needs /root/reference)")
+        gen_capture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ofast":
         if not (ob.have_reference() and ob.have_reference_ofast()):
             sys.exit("oracle/_ref/libsdrref.so / libsdrref_ofast.so missing: run `make -C oracle/ref` first (needs /root/reference)")
@@ -244,6 +303,7 @@ if __name__ == "__main__":
         sys.exit("oracle/_ref/libsdrref.so missing: run `make -C oracle/ref` first (needs /root/reference)")
     gen_primitives()
     gen_chains()
+    gen_capture()
     gen_zmq()
     gen_dropin()
     if ob.have_reference_ofast():

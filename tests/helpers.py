@@ -105,6 +105,32 @@ def check_against_ofast_fixture(g, topo, f, stream_of, payload_of, o2_payload_of
     return worst, patched, total
 
 
+# ---- the capture-like stream (tests/golden/capture_25e.npz; BASELINE.json north_star: "on recorded IQ") -------------------------
+def capture_frames():
+    """(fixture, topology, [dongle bytes of frame 0, 1, ...]): sdrreceiver_amd.synth.capture_like_u8 regenerated and checked
+    against the sha256 the fixture was made from (another numpy / libm could round a sample differently: then the fixture
+    does not apply and the tests say so instead of comparing apples with pears)."""
+    import pytest
+    from sdrreceiver_amd import synth, topology as tp
+    g = golden("capture_25e.npz")
+    topo = tp.profile_25e()
+    n = int(g["frames"])
+    u8 = synth.capture_like_u8(n, topo.frame, topo.fs)
+    if hashlib.sha256(u8.tobytes()).hexdigest() != str(g["input_sha256"]):
+        pytest.skip("capture_like_u8 does not reproduce the bytes capture_25e.npz was generated from on this numpy build")
+    return g, topo, [u8[2 * topo.frame * f: 2 * topo.frame * (f + 1)] for f in range(n)]
+
+
+def check_capture_frame_exact(g, topo, f, stream_of, payload_of):
+    """Frame `f` against the -O2 reference's outputs in the fixture: sha256 of every final complex stream and of every int16
+    payload (stream_of(i) may return None where an implementation keeps no decimate[0])."""
+    for i, v in enumerate(topo.vfos):
+        z = stream_of(i)
+        assert z is None or sha(z) == str(g[f"f{f}_v{i}_stream_sha"]), (f, i, "stream")
+        if not topo.children(i):
+            assert sha(payload_of(i)) == str(g[f"f{f}_v{i}_pay_sha"]), (f, i, "payload")
+
+
 # ---- seeded random trees (tests/test_gpu_parity.py, tests/test_dropin_qt.py, tools/dropin_run.py random:<seed>) ----------
 def random_topology(rng):
     """A random tree inside the library's documented restrictions: 1-3 levels, depths 0-4, frames of

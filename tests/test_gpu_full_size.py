@@ -148,7 +148,7 @@ def _every_sub_vfo_against_the_oracle(topo, n_frames, queued=False, **options):
             assert len(rx.published) == len(subs)
             got[f] = digests()
     rx.close()
-    threads = max(1, len(os.sched_getaffinity(0)))
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
     checked = 0
     for b in range(0, len(subs), 1024):
         batch = subs[b:b + 1024]
@@ -203,7 +203,7 @@ def _every_sub_vfo_within_tolerance(topo, n_frames):
     assert len(rx.published) == len(subs)
     got = {i: (rx.output(i), rx.stream(i, missing_ok=True), rx.prequant(i)) for i in subs}
     rx.close()
-    threads = max(1, len(os.sched_getaffinity(0)))
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
     worst_s = worst_p = 0.0
     differing = total = 0
     for b in range(0, len(subs), 1024):

@@ -160,6 +160,46 @@ def test_against_the_reference_as_shipped(Receiver, fixture, exact):
     rx.close()
 
 
+@pytest.mark.parametrize("arith", ["exact", "tolerance"])
+@pytest.mark.parametrize("entry", ["bytes, DC removal on the device", "floats, DC removal on the host"])
+def test_capture_like_stream_through_the_shipped_profile(Receiver, arith, entry):
+    """BASELINE.json north_star: "match the reference CPU path ... on recorded IQ".  The reference holds no recording, so: the
+    seeded capture-like byte stream (tests/golden/capture_25e.npz was made from it by the REAL reference build, -O2 and
+    -Ofast: tuner noise, carriers that take the bytes past +-100, an ADC offset, BPSK / OQPSK bursts on sdr_25E VFO
+    frequencies, int16 audio up to 29 656) through the shipped sdr_25E profile with correct_dc_bias=1, 8 frames = 2 s.
+    Exact arithmetic: every stream and payload sha-identical to the -O2 reference's.  Tolerance arithmetic: every stream and
+    pre-quantisation float within 1e-5 of max|ref|, int16 within 1 LSB of the -O2 AND of the shipped -Ofast build's.
+    Both ingest forms: dongle bytes with LUT + DC-bias removal on the device (sdrx_process_u8: sdrj.cpp:155-160,271-286),
+    and floats after the host-side DC removal (sdrx_process: sdrj::demodData's own argument)."""
+    from helpers import capture_frames, check_capture_frame_exact
+    g, topo, frames = capture_frames()
+    exact = arith == "exact"
+    rx = Receiver.from_topology(topo, exact=exact, keep_prequant=not exact)
+    nodes, roots = ob.build_tree("port", topo)
+    state = np.zeros(2, np.float32)
+    for f, b in enumerate(frames):
+        iq = ob.u8_to_float(b)
+        ob.dc_correct(iq, state)
+        if entry.startswith("bytes"):
+            rx.process_u8(b, correct_dc=True)
+        else:
+            rx.process(iq)
+        if exact:
+            check_capture_frame_exact(g, topo, f, rx.stream, rx.output)
+            continue
+        ob.process_roots(roots, iq, threads=4)
+        _check_tolerance(rx, nodes, topo, ("capture", f))
+        for i, v in enumerate(topo.vfos):
+            z = rx.stream(i)
+            e = float(np.abs(z[::128] - g[f"f{f}_v{i}_ofast_stream_every128"]).max()) / float(g[f"f{f}_v{i}_ofast_stream_absmax"])
+            assert e <= REL_TOL, (f, i, "stream vs the -Ofast build", e)
+            if not topo.children(i):
+                shipped = nodes[i].usb().copy()
+                shipped[g[f"f{f}_v{i}_ofast_pay_idx"]] = g[f"f{f}_v{i}_ofast_pay_val"]
+                assert np.abs(rx.output(i).astype(np.int32) - shipped.astype(np.int32)).max() <= 1, (f, i, "int16 vs the -Ofast build")
+    rx.close()
+
+
 @pytest.mark.parametrize("key,frames", [("config1", 5), ("profile_25e", 3), ("54w", 3), ("288k", 3)])
 def test_fast_mode_within_tolerance(Receiver, key, frames):
     topo = golden_topology(key)

@@ -134,3 +134,30 @@ def test_oracle_against_the_shipped_ofast_build(fixture):
         ob.process_roots(roots, synth.lcg_frame(topo.frame, lcg))
         worst, patched, total = check_against_ofast_fixture(g, topo, f, lambda i: nodes[i].stream(), lambda i: nodes[i].usb())
         assert worst < 1e-6 and patched * 1000 < total
+
+
+def test_capture_like_stream_through_the_shipped_profile():
+    """BASELINE.json north_star's "recorded IQ", as far as this repository can have it (the reference ships no recording): the
+    seeded capture-like byte stream (tuner noise, carriers past +-100, ADC offset, BPSK / OQPSK bursts on sdr_25E VFO
+    frequencies, int16 audio to 29 656 of 32 767) through the whole sdr_25E profile with correct_dc_bias=1 -- the plain-C oracle
+    against what the REAL reference build produced (tests/golden/make_golden.py capture): every stream, every payload, 8
+    frames, bit for bit; and against the -Ofast build's payloads, rebuilt from the patch, within 1 LSB."""
+    from helpers import capture_frames, check_capture_frame_exact
+    g, topo, frames = capture_frames()
+    nodes, roots = ob.build_tree("port", topo)
+    state = np.zeros(2, np.float32)
+    peak = 0
+    for f, b in enumerate(frames):
+        iq = ob.u8_to_float(b)
+        ob.dc_correct(iq, state)
+        assert np.array_equal(bits(state), bits(g[f"f{f}_dc_state"])) and sha(iq) == str(g[f"f{f}_raw_sha"])
+        ob.process_roots(roots, iq, threads=4)
+        check_capture_frame_exact(g, topo, f, lambda i: nodes[i].stream(), lambda i: nodes[i].usb())
+        for i, v in enumerate(topo.vfos):
+            if not topo.children(i):
+                a = nodes[i].usb()
+                peak = max(peak, int(np.abs(a.astype(np.int32)).max()))
+                shipped = a.copy()
+                shipped[g[f"f{f}_v{i}_ofast_pay_idx"]] = g[f"f{f}_v{i}_ofast_pay_val"]
+                assert sha(shipped) == str(g[f"f{f}_v{i}_ofast_pay_sha"]) and np.abs(shipped.astype(np.int32) - a).max() <= 1, (f, i)
+    assert 26000 < peak < 32768  # near full scale, never past it (a wrapped sample would make "+-1 LSB" meaningless)
