@@ -314,8 +314,12 @@ def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix
         slots = v["valu_insts"] * (1.0 - v.get("dual_issued_frac", 0.0) / 2.0)  # issue slots carrying an instruction
         r["bound"], r["unit"] = "valu", "G VALU issue slots/s"
         r["achieved"] = round(slots / (v["pass_dur_us"] * 1e3), 1)
-        r["peak"] = round(r["achieved"] / busy, 1) if busy > 0 else None  # = 1024 SIMDs x clock / 4 x what a saturated probe reads
-        r["frac"] = round(busy, 4)
+        # the peak from the hardware and the calibration alone: 1024 SIMDs x one VALU issue slot per 4 cycles at the clock the
+        # counters of that pass saw, x what a saturated probe of the same instruction mix reads under the same counters
+        # (tools/valu_calib.hip).  frac = achieved / peak is then a CHECK of the calibrated busy reading (`valu.busy`, derived
+        # from the cycle counter instead of the duration), not an identity: tests/test_bench_contract.py holds the two together.
+        r["peak"] = round(N_SIMD * v["clock_GHz"] / 4.0 * v.get("probe_reads_raw", 1.0), 1)
+        r["frac"] = round(min(1.0, r["achieved"] / r["peak"]), 4)
         r["limited_by"] = (f"VALU issue: {busy:.0%} of the launch's issue slots carry a VALU instruction (calibrated) -- not HBM: "
                            + (f"real traffic is {hb:.0%} of the 8 TB/s peak, siblings share the parent's stream through L2" if hb is not None
                               else "no traffic counters"))

@@ -66,17 +66,26 @@ struct Tree {
     int device = 0;
     bool pipelined = false;    // SDRX_PIPELINE=1
     int in_flight = 0;         // frames submitted and not yet delivered
-    const vfo *tap = nullptr;  // the node sdrx_set_tap was last told about (fftVFOSlot) ...
-    sdrx_ctx *tap_ctx = nullptr; // ... and the context that holds it
+    std::vector<const vfo *> taps;      // the nodes the library was last told about (fftVFOSlot -> sdrx_add_tap) ...
+    std::vector<sdrx_ctx *> tap_ctxs;   // ... and the contexts that hold them
+    long dropped = 0;                   // frames lost to a runtime error of the device path (logged, never fatal)
     ~Tree();
     const char *error() const { return grp ? sdrx_group_last_error(grp) : sdrx_last_error(ctx); }
-    // deliver the oldest submitted frame: payloads -> transmit buffers -> ZmqPublisher, in the reference's order
+    // deliver the oldest submitted frame: payloads -> transmit buffers -> ZmqPublisher, in the reference's order.
+    // The reference's hot path cannot fail (every function on it is void; a buffer the dongle thread could not hand over is
+    // a time gap and a qDebug line, jonti/sdr.cpp:105-110): a runtime error of the device path is the same kind of event --
+    // the frame is dropped and logged, the receiver (and the GUI around it) keeps running.
     void deliver_one()
     {
         cursor = 0;
         if ((grp ? sdrx_group_wait(grp) : sdrx_wait(ctx)) != SDRX_OK)
-            qFatal("sdrx adapter: sdrx_wait: %s", error());
+            drop("sdrx_wait");
         --in_flight;
+    }
+    void drop(const char *what)
+    {
+        ++dropped;
+        qWarning("sdrx adapter: %s failed, frame dropped (%ld so far): %s", what, dropped, error());
     }
 };
 
@@ -348,31 +357,33 @@ void vfo::process(const std::vector<cpx_typef> &samples)
     // fftVFOSlot selected a node of this tree (vfo.cpp:492-509): the library must know BEFORE the frame runs -- a leaf whose
     // late decimation is fused into the mix wave keeps decimate[0] only while it is the tap (sdrx_set_tap)
     {
-        const vfo *want = nullptr;
+        std::vector<const vfo *> want; // (vfo::fftVFOSlot sets emitFFT on EVERY VFO whose topic matches, vfo.cpp:492-509)
         for (vfo *v : T.nodes)
-            if (v->emitFFT) {
-                want = v;
-                break;
-            }
-        if (want != T.tap) {
+            if (v->emitFFT)
+                want.push_back(v);
+        if (want != T.taps) {
             while (T.in_flight > 0)
                 T.deliver_one();
-            if (T.tap_ctx && sdrx_set_tap(T.tap_ctx, -1) != SDRX_OK)
-                qFatal("sdrx adapter: sdrx_set_tap: %s", sdrx_last_error(T.tap_ctx));
-            T.tap_ctx = nullptr;
-            if (want) {
-                int id = side()[want].id;
+            bool ok = true;
+            for (sdrx_ctx *c : T.tap_ctxs)
+                ok = sdrx_set_tap(c, -1) == SDRX_OK && ok;
+            T.tap_ctxs.clear();
+            for (const vfo *w : want) {
+                int id = side()[w].id;
                 sdrx_ctx *c = T.ctx;
                 if (T.grp) {
                     int member = -1;
                     if (sdrx_group_locate(T.grp, id, &member, &id) != SDRX_OK || sdrx_group_member(T.grp, member, &c, nullptr) != SDRX_OK || !c)
-                        qFatal("sdrx adapter: sdrx_group_locate: %s", T.error());
+                        qFatal("sdrx adapter: sdrx_group_locate: %s", T.error()); // (a VFO of this very tree: misuse, not a runtime event)
                 }
-                if (sdrx_set_tap(c, id) != SDRX_OK)
-                    qFatal("sdrx adapter: sdrx_set_tap: %s", sdrx_last_error(c));
-                T.tap_ctx = c;
+                ok = sdrx_add_tap(c, id) == SDRX_OK && ok;
+                if (std::find(T.tap_ctxs.begin(), T.tap_ctxs.end(), c) == T.tap_ctxs.end())
+                    T.tap_ctxs.push_back(c);
             }
-            T.tap = want;
+            if (!ok) // (the selection is retried with the next frame: T.taps stays what it was)
+                qWarning("sdrx adapter: selecting the spectrum tap failed: %s", T.error());
+            else
+                T.taps = want;
         }
     }
     // Who uploads: this tree -- unless the tree that uploaded last on this device holds exactly these samples (sdrj::demodData
@@ -388,16 +399,20 @@ void vfo::process(const std::vector<cpx_typef> &samples)
         shared = rc == SDRX_OK;
         if (rc == SDRX_DIFFERENT)
             rc = T.grp ? sdrx_group_process(T.grp, iq, n) : sdrx_process(T.ctx, iq, n);
-        if (rc != SDRX_OK)
-            qFatal("sdrx adapter: sdrx_process: %s", T.error());
+        if (rc != SDRX_OK) {
+            T.drop("sdrx_process");
+            return;
+        }
     } else {
         // submit(f); deliver f-1 -- or everything, while a spectrum tap wants this very frame's streams
         int rc = from ? sdrx_submit_if_same(T.ctx, from, iq, n) : SDRX_DIFFERENT;
         shared = rc == SDRX_OK;
         if (rc == SDRX_DIFFERENT)
             rc = T.grp ? sdrx_group_submit(T.grp, iq, n) : sdrx_submit(T.ctx, iq, n);
-        if (rc != SDRX_OK)
-            qFatal("sdrx adapter: sdrx_submit: %s", T.error());
+        if (rc != SDRX_OK) {
+            T.drop("sdrx_submit");
+            return;
+        }
         ++T.in_flight;
         while (T.in_flight > (want_fft ? 0 : 1))
             T.deliver_one();
@@ -413,12 +428,16 @@ void vfo::process(const std::vector<cpx_typef> &samples)
                 if (sdrx_group_locate(T.grp, id, &member, &id) != SDRX_OK || sdrx_group_member(T.grp, member, &c, nullptr) != SDRX_OK || !c)
                     qFatal("sdrx adapter: sdrx_group_locate: %s", T.error());
             }
-            if (sdrx_get_stream(c, id, nullptr, 0, &n) != SDRX_OK)
-                qFatal("sdrx adapter: sdrx_get_stream: %s", sdrx_last_error(c));
+            if (sdrx_get_stream(c, id, nullptr, 0, &n) != SDRX_OK) { // (e.g. selected too late for this frame: no spectrum this time)
+                qWarning("sdrx adapter: sdrx_get_stream: %s", sdrx_last_error(c));
+                continue;
+            }
             std::vector<cpx_typef> &dst = v->decimate[v->decimateCount];
             dst.resize((size_t)n);
-            if (sdrx_get_stream(c, id, reinterpret_cast<float *>(dst.data()), n, &n) != SDRX_OK)
-                qFatal("sdrx adapter: sdrx_get_stream: %s", sdrx_last_error(c));
+            if (sdrx_get_stream(c, id, reinterpret_cast<float *>(dst.data()), n, &n) != SDRX_OK) {
+                qWarning("sdrx adapter: sdrx_get_stream: %s", sdrx_last_error(c));
+                continue;
+            }
             emit v->fftData(dst);
         }
 }

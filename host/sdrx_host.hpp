@@ -205,27 +205,28 @@ private:
         check(sdrx_group_member(grp_, member, &c, nullptr), "sdrx_group_member");
         return c;
     }
-    // fftVFOSlot selected a VFO (vfo.cpp:492-509): tell the library before the frame runs -- a leaf whose late decimation
-    // is fused into the mix wave keeps decimate[0] only while it is the tap (sdrx_set_tap)
+    // fftVFOSlot selected VFOs (vfo.cpp:492-509: EVERY VFO whose topic equals the selected string): tell the library before the
+    // frame runs -- a leaf whose late decimation is fused into the mix wave keeps decimate[0] only while it is a tap
+    // (sdrx_set_tap replaces the selection of a context, sdrx_add_tap adds to it)
     void select_tap()
     {
-        vfo *want = nullptr;
+        std::vector<vfo *> want;
         for (vfo *v : all_)
-            if (v->emitFFT && v->fftData) {
-                want = v;
-                break;
-            }
-        if (want == tap_vfo_)
+            if (v->emitFFT && v->fftData)
+                want.push_back(v);
+        if (want == taps_)
             return;
-        if (tap_ctx_)
-            check_ctx(tap_ctx_, sdrx_set_tap(tap_ctx_, -1), "sdrx_set_tap");
-        tap_ctx_ = nullptr;
-        if (want) {
+        for (sdrx_ctx *c : tap_ctxs_)
+            check_ctx(c, sdrx_set_tap(c, -1), "sdrx_set_tap");
+        tap_ctxs_.clear();
+        for (vfo *v : want) {
             int lid = -1;
-            tap_ctx_ = locate(want->id, &lid);
-            check_ctx(tap_ctx_, sdrx_set_tap(tap_ctx_, lid), "sdrx_set_tap");
+            sdrx_ctx *c = locate(v->id, &lid);
+            check_ctx(c, sdrx_add_tap(c, lid), "sdrx_add_tap");
+            if (std::find(tap_ctxs_.begin(), tap_ctxs_.end(), c) == tap_ctxs_.end())
+                tap_ctxs_.push_back(c);
         }
-        tap_vfo_ = want;
+        taps_ = want;
     }
     // vfo::process ends with `if (emitFFT) emit fftData(decimate[decimateCount])` (vfo.cpp:290-293);
     // demodData with `if (count == 4 && emitFFT) { emit fftData(samples); count = 0; } count++`.
@@ -306,8 +307,8 @@ private:
     int count = 0;
     std::vector<vfo *> all_;
     std::vector<std::complex<float>> tap_;
-    vfo *tap_vfo_ = nullptr;     // the VFO sdrx_set_tap was last told about ...
-    sdrx_ctx *tap_ctx_ = nullptr; // ... and the context that holds it
+    std::vector<vfo *> taps_;          // the VFOs the library was last told about (sdrx_add_tap) ...
+    std::vector<sdrx_ctx *> tap_ctxs_; // ... and the contexts that hold them
     float avept_[2] = {0.f, 0.f};
     std::vector<float> samples_;
     publish_fn publish_;

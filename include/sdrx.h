@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SDRX_ABI_VERSION 4
+#define SDRX_ABI_VERSION 5
 
 enum {
     SDRX_OK = 0,
@@ -34,7 +34,8 @@ enum {
                         /* from firfilter::sanity_check_1f (firfilter.cpp:122-134)       */
     SDRX_EHIP = -4,     /* HIP runtime error                                             */
     SDRX_EUNSUPPORTED = -5, /* geometry outside what the kernels handle (see sdrx_finalize) */
-    SDRX_ENOMEM = -6
+    SDRX_ENOMEM = -6,
+    SDRX_ENOSTREAM = -7 /* sdrx_get_stream: this VFO keeps no decimate[d] (a fused /5 | /6 leaf that is not a tap)  */
 };
 
 typedef struct sdrx_ctx sdrx_ctx;
@@ -208,12 +209,15 @@ int sdrx_get_output(sdrx_ctx *ctx, int id, const void **buf, uint32_t *len_bytes
 /* decimate[decimateCount] of node `id` (public member vfo.h:39 -- what the fftData signal
  * carries, vfo.cpp:290-293): copies up to max_complex cf32 to `out`, returns the count in *n. */
 int sdrx_get_stream(sdrx_ctx *ctx, int id, float *out_iq, int max_complex, int *n);
-/* fftVFOSlot(topic) (vfo.cpp:492-509, sdrj.cpp:84-101): the GUI names ONE VFO whose decimate[decimateCount] it wants
- * from the next frame on.  Every node keeps that stream in HBM anyway, with one exception: a leaf whose late decimation
- * is fused into the mix wave (option "fuse_late") writes only its decimated stream -- sdrx_get_stream on it returns
- * SDRX_ESTATE unless it was selected here before the frame was processed (or "keep_streams" is set).  id = -1: none.
- * Not while submitted frames are in flight. */
+/* fftVFOSlot(topic) (vfo.cpp:492-509, sdrj.cpp:84-101): the GUI names the VFO(s) whose decimate[decimateCount] it wants
+ * from the next frame on -- every VFO whose topic equals the selected string gets emitFFT, so an INI with one topic on two
+ * VFOs (or several empty topics) has several taps.  Every node keeps that stream in HBM anyway, with one exception: a leaf
+ * whose late decimation is fused into the mix wave (option "fuse_late") writes only its decimated stream -- sdrx_get_stream
+ * on it returns SDRX_ENOSTREAM unless it was selected here before the frame was processed (or "keep_streams" is set).
+ * sdrx_set_tap REPLACES the selection by `id` (-1: nothing selected: a deselected leaf stops writing its decimate[0]);
+ * sdrx_add_tap adds `id` to it.  Not while submitted frames are in flight; contexts are single-caller (one thread). */
 int sdrx_set_tap(sdrx_ctx *ctx, int id);
+int sdrx_add_tap(sdrx_ctx *ctx, int id);
 /* The raw frame exactly as the parent-less VFOs consumed it -- `samples` of sdrj::demodData
  * (sdrj.cpp:266-305) after the byte LUT and the DC-bias removal, what sdrj's own fftData signal
  * carries (sdrj.cpp:296-303) -- natural order, cf32.  Available after sdrx_process and

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("SDRX_LIB") or os.path.join(_HERE, "libsdrx.so")  # SD
 CSRC = os.path.join(_HERE, "csrc")
 
 NKERNELS = 8
-SDRX_EINVAL, SDRX_ESTATE, SDRX_EFILTER, SDRX_EHIP, SDRX_EUNSUPPORTED = -1, -2, -3, -4, -5  # include/sdrx.h
+SDRX_EINVAL, SDRX_ESTATE, SDRX_EFILTER, SDRX_EHIP, SDRX_EUNSUPPORTED, SDRX_ENOMEM, SDRX_ENOSTREAM = -1, -2, -3, -4, -5, -6, -7  # include/sdrx.h
 SDRX_DIFFERENT = 1  # sdrx_*_if_same: the frame is not the one the source context staged
 
 
@@ -71,6 +71,7 @@ SYMBOLS = {
     "sdrx_get_output": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sdrx_get_stream": (_i, [_vp, _i, _vp, _i, C.POINTER(_i)]),
     "sdrx_set_tap": (_i, [_vp, _i]),
+    "sdrx_add_tap": (_i, [_vp, _i]),
     "sdrx_get_raw": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     "sdrx_get_prequant": (_i, [_vp, _i, _vp, _i, C.POINTER(_i)]),
     "sdrx_get_taps": (_i, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),

@@ -113,9 +113,16 @@ struct sdrx_ctx {
     bool finalized = false;
     int opt_exact = 1, opt_prequant = 0, opt_segments = 0, opt_dc_blocked = 0, opt_pipeline = 0;
     int opt_fuse = 1, opt_frame_pipeline = 1, opt_fuse_late = 1, opt_keep_streams = 0;
-    int tap_id = -1;                  // sdrx_set_tap: the node whose decimate[d] sdrx_get_stream is asked for
-    unsigned long long tap_since = 0; // first frame that keeps it
-    size_t tap_len = 0, off_tapbuf[2] = {0, 0}; // where a fused leaf keeps decimate[0] while it is the tap, per frame parity
+    // sdrx_set_tap / sdrx_add_tap: the fused late-decimation leaves that keep decimate[0] because they are taps (vfo::fftVFOSlot
+    // sets emitFFT on EVERY VFO whose topic matches, vfo.cpp:492-509): node -> its buffers per frame parity and the first
+    // frame that fills them.  The first such leaf uses the arena's buffer, further ones buffers of their own (hipMalloc).
+    struct TapBuf {
+        float2 *buf[2] = {nullptr, nullptr};
+        unsigned long long since = 0;
+        bool own = false;
+    };
+    std::map<int, TapBuf> taps;
+    size_t tap_len = 0, off_tapbuf[2] = {0, 0}; // the arena's tap buffer (sized for the longest fused leaf), per frame parity
     LevelPlan fp;
     std::vector<InFlight> pipe; // oldest first
     sdrx_publish_fn cb = nullptr;
@@ -526,6 +533,11 @@ void free_device_state(sdrx_ctx *c)
             (void)hipHostFree(p);
         p = nullptr;
     };
+    for (auto &kv : c->taps)
+        if (kv.second.own)
+            for (int p = 0; p < 2; ++p)
+                (void)hipFree(kv.second.buf[p]);
+    c->taps.clear();
     dfree(c->arena);
     for (int p = 0; p < 2; ++p) {
         dfree(c->d_pay[p]);
@@ -1409,7 +1421,7 @@ int finalize_impl(sdrx_ctx *c)
     if (int rc = allocate_and_upload(c, B))
         return rc;
     build_publish_order(c);
-    c->tap_id = -1;
+    c->taps.clear();
     c->finalized = true;
     return SDRX_OK;
 }
@@ -1440,39 +1452,65 @@ int sdrx_finalize(sdrx_ctx *c)
 
 // The reference's fftVFOSlot(topic) (vfo.cpp:492-509): from the next frame on, decimate[decimateCount] of node `id` is what
 // sdrx_get_stream serves.  Every VFO keeps that stream in HBM anyway -- except a leaf whose late decimation runs inside the
-// mix wave (it writes only the decimated stream): for such a leaf this call makes the wave keep decimate[0] as well, one
-// leaf at a time.  id = -1: none.
-int sdrx_set_tap(sdrx_ctx *c, int id)
+// mix wave (it writes only the decimated stream): for such a leaf this call makes the wave keep decimate[0] as well.
+// sdrx_set_tap REPLACES the selection (id = -1: none), sdrx_add_tap adds to it: fftVFOSlot sets emitFFT on every VFO whose
+// topic equals the selected string, so two VFOs with one topic are two taps.
+static int tap_change(sdrx_ctx *c, int id, bool replace, const char *what)
 {
     if (!c)
         return SDRX_EINVAL;
     if (!c->finalized)
-        return fail(c, SDRX_ESTATE, "sdrx_set_tap before sdrx_finalize");
-    if (id < -1 || id >= (int)c->nodes.size())
+        return fail(c, SDRX_ESTATE, "%s before sdrx_finalize", what);
+    if (id < (replace ? -1 : 0) || id >= (int)c->nodes.size())
         return fail(c, SDRX_EINVAL, "bad vfo id %d", id);
     if (c->in_flight > 0)
-        return fail(c, SDRX_ESTATE, "sdrx_set_tap: %d submitted frame(s) not yet delivered -- call sdrx_wait first", c->in_flight);
+        return fail(c, SDRX_ESTATE, "%s: %d submitted frame(s) not yet delivered -- call sdrx_wait first", what, c->in_flight);
     HIPCHK(c, hipSetDevice(c->device));
-    if (int rc = drain(c)) // frames inside the software pipeline run to their end with the tap they were queued under
+    if (int rc = drain(c)) // frames inside the software pipeline run to their end with the taps they were queued under
         return rc;
-    auto set = [&](int node, bool on) -> hipError_t {
-        float2 *ptrs[2] = {nullptr, nullptr};
-        for (int p = 0; p < 2 && on; ++p)
-            ptrs[p] = reinterpret_cast<float2 *>(c->arena + c->off_tapbuf[p]);
-        return hipMemcpyAsync(c->arena + c->off_k1vfo + sizeof(K1Vfo) * (size_t)node + offsetof(K1Vfo, tap), ptrs, sizeof ptrs,
-                              hipMemcpyHostToDevice, c->stream);
+    auto point = [&](int node, float2 *b0, float2 *b1) -> hipError_t { // K1Vfo::tap of `node` (synchronous: the pointers live on this stack)
+        float2 *ptrs[2] = {b0, b1};
+        return hipMemcpy(c->arena + c->off_k1vfo + sizeof(K1Vfo) * (size_t)node + offsetof(K1Vfo, tap), ptrs, sizeof ptrs, hipMemcpyHostToDevice);
     };
-    auto needs_buffer = [&](int node) { return node >= 0 && !c->nodes[(size_t)node].has_stream; };
-    if (needs_buffer(c->tap_id) && c->tap_id != id)
-        HIPCHK(c, set(c->tap_id, false));
-    if (needs_buffer(id) && c->tap_id != id) {
-        HIPCHK(c, set(id, true));
-        c->tap_since = c->frame_no;
+    if (replace) {
+        for (auto it = c->taps.begin(); it != c->taps.end();) {
+            if (it->first == id) { // stays what it is (and keeps serving the frames it has)
+                ++it;
+                continue;
+            }
+            HIPCHK(c, point(it->first, nullptr, nullptr));
+            if (it->second.own)
+                for (int p = 0; p < 2; ++p)
+                    (void)hipFree(it->second.buf[p]);
+            it = c->taps.erase(it);
+        }
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream)); // (the two pointers above live on this call's stack)
-    c->tap_id = id;
+    if (id < 0 || c->nodes[(size_t)id].has_stream || c->taps.count(id))
+        return SDRX_OK; // every other node keeps decimate[d] in HBM anyway
+    sdrx_ctx::TapBuf t;
+    t.since = c->frame_no;
+    bool arena_free = c->tap_len > 0;
+    for (const auto &kv : c->taps)
+        arena_free = arena_free && kv.second.own;
+    if (arena_free) {
+        for (int p = 0; p < 2; ++p)
+            t.buf[p] = reinterpret_cast<float2 *>(c->arena + c->off_tapbuf[p]);
+    } else {
+        t.own = true;
+        for (int p = 0; p < 2; ++p)
+            if (hipMalloc(&t.buf[p], sizeof(float2) * (size_t)c->nodes[(size_t)id].n_f) != hipSuccess) {
+                if (t.buf[0])
+                    (void)hipFree(t.buf[0]);
+                return fail(c, SDRX_ENOMEM, "%s: no device memory for another tap buffer", what);
+            }
+    }
+    HIPCHK(c, point(id, t.buf[0], t.buf[1]));
+    c->taps.emplace(id, t);
     return SDRX_OK;
 }
+
+int sdrx_set_tap(sdrx_ctx *c, int id) { return tap_change(c, id, true, "sdrx_set_tap"); }
+int sdrx_add_tap(sdrx_ctx *c, int id) { return tap_change(c, id, false, "sdrx_add_tap"); }
 
 int sdrx_set_stream(sdrx_ctx *c, void *s)
 {
@@ -1892,14 +1930,15 @@ int sdrx_get_stream(sdrx_ctx *c, int id, float *out, int max_complex, int *n_ret
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = drain(c))
         return rc;
-    if (!n.has_stream && !(c->tap_id == id && c->frame_no > c->tap_since))
-        return fail(c, SDRX_ESTATE,
-                    "sdrx_get_stream: vfo %d decimates by %d inside the mix wave and keeps no decimate[0] -- select it with sdrx_set_tap "
-                    "before the frame (the reference's fftVFOSlot), or set option keep_streams=1 / fuse_late=0",
+    const auto tap = c->taps.find(id);
+    if (!n.has_stream && !(tap != c->taps.end() && c->frame_no > tap->second.since))
+        return fail(c, SDRX_ENOSTREAM,
+                    "sdrx_get_stream: vfo %d decimates by %d inside the mix wave and keeps no decimate[0] -- select it with sdrx_set_tap / "
+                    "sdrx_add_tap before the frame (the reference's fftVFOSlot), or set option keep_streams=1 / fuse_late=0",
                     id, n.fused_late);
     if (out && cnt > 0) {
         if (!n.has_stream) {
-            HIPCHK(c, hipMemcpy(out, c->arena + c->off_tapbuf[par], sizeof(float2) * (size_t)cnt, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(out, tap->second.buf[par], sizeof(float2) * (size_t)cnt, hipMemcpyDeviceToHost));
         } else if (n.leaf) {
             HIPCHK(c, hipMemcpy(out, c->arena + n.off_stream[par] + sizeof(float2) * (size_t)n.Hx, sizeof(float2) * (size_t)cnt,
                                 hipMemcpyDeviceToHost));

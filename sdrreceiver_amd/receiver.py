@@ -191,7 +191,7 @@ class Receiver:
         or None with `missing_ok`."""
         n = C.c_int()
         rc = self.L.sdrx_get_stream(self.h, vid, None, 0, C.byref(n))
-        if rc == _lib.SDRX_ESTATE and missing_ok and b"keeps no decimate[0]" in self.L.sdrx_last_error(self.h):
+        if rc == _lib.SDRX_ENOSTREAM and missing_ok:
             return None
         self._chk(rc)
         out = np.zeros(2 * max(n.value, 1), np.float32)
@@ -199,8 +199,19 @@ class Receiver:
         return out[: 2 * n.value].view(np.complex64).copy()
 
     def set_tap(self, vid: int) -> None:
-        """fftVFOSlot: from the next frame on :meth:`stream` serves VFO `vid` whatever its kind (-1: none)."""
+        """fftVFOSlot: from the next frame on :meth:`stream` serves VFO `vid` whatever its kind; REPLACES the selection
+        (-1: nothing selected)."""
         self._chk(self.L.sdrx_set_tap(self.h, int(vid)))
+
+    def add_tap(self, vid: int) -> None:
+        """One more tapped VFO (fftVFOSlot sets emitFFT on every VFO whose topic matches, vfo.cpp:492-509)."""
+        self._chk(self.L.sdrx_add_tap(self.h, int(vid)))
+
+    def set_taps(self, vids) -> None:
+        """The selection becomes exactly `vids`."""
+        self.set_tap(-1)
+        for v in vids:
+            self.add_tap(v)
 
     def raw(self) -> np.ndarray:
         """The raw frame as the main VFOs consumed it (after the byte LUT / DC-bias removal)."""
@@ -322,7 +333,7 @@ class Group:
         ctx, _ = self.member_context(m)
         n = C.c_int()
         rc = self.L.sdrx_get_stream(ctx, lid, None, 0, C.byref(n))
-        if rc == _lib.SDRX_ESTATE and missing_ok and b"keeps no decimate[0]" in self.L.sdrx_last_error(ctx):
+        if rc == _lib.SDRX_ENOSTREAM and missing_ok:
             return None
         if rc != 0:
             raise SdrxError(rc, self.L.sdrx_last_error(ctx).decode())
@@ -427,8 +438,8 @@ class vfo:  # noqa: N801  (the reference's class name, vfo.h:11)
         """vfo.cpp:492-509: this VFO's decimate[decimateCount] goes to ``fftData`` after every
         frame while the selected topic is its own."""
         self.emitFFT = str(topic) == self.desc.topic
-        if self.emitFFT and self._radio is not None and self._radio.rx is not None:
-            self._radio.rx.set_tap(self._id)
+        if self._radio is not None and self._radio.rx is not None:
+            self._radio._sync_taps()  # (a deselected fused leaf stops writing its decimate[0]; several VFOs may share a topic)
 
     # observation, available once the owning sdrj has started
     def _r(self) -> Receiver:
@@ -477,6 +488,10 @@ class sdrj:  # noqa: N801  (the reference's class name, sdrj.h)
             yield v
             stack[0:0] = v.children
 
+    def _sync_taps(self):
+        """The library's selection = the VFOs with emitFFT (every VFO whose topic equals the selected string, vfo.cpp:492-509)."""
+        self.rx.set_taps([v._id for v in self._all_vfos() if v.emitFFT])
+
     def _after_frame(self):
         # vfo::process ends with `if (emitFFT) emit fftData(decimate[decimateCount])` (vfo.cpp:290-293),
         # demodData with the every-4th-call raw tap (sdrj.cpp:296-303)
@@ -506,9 +521,7 @@ class sdrj:  # noqa: N801  (the reference's class name, sdrj.h)
         for m in self.mains:
             add(m, -1)
         self.rx.finalize()
-        for v in self._all_vfos():  # a selection made before the tree existed (fftVFOSlot, vfo.cpp:492-509)
-            if v.emitFFT:
-                self.rx.set_tap(v._id)
+        self._sync_taps()  # a selection made before the tree existed (fftVFOSlot, vfo.cpp:492-509)
 
     def demodData(self, data, length=None):
         if self.rx is None:

@@ -22,7 +22,7 @@ def test_header_and_binding_agree():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.sdrx_abi_version() == 4
+    assert L.sdrx_abi_version() == 5
     assert L.sdrx_kernel_name(1).decode().startswith("k_mix_decimate")
 
 

@@ -119,7 +119,7 @@ def test_header_is_plain_c_and_fails_loudly_without_a_gpu():
     import torch
     _build()
     r = subprocess.run([os.path.join(ROOT, "host", "abi_check")], capture_output=True, text=True)
-    assert "sdrx ABI version 4, sizeof(sdrx_vfo_desc) = 56" in r.stdout
+    assert "sdrx ABI version 5, sizeof(sdrx_vfo_desc) = 56" in r.stdout
     if not torch.cuda.is_available():
         assert r.returncode == 3 and "no CPU fallback" in r.stderr
 
