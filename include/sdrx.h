@@ -116,13 +116,17 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
  *   "keep_streams" 0 (default) | 1: every such leaf also keeps decimate[0] of every frame (parity tests that
  *            compare every stream of the tree).
  *   "dc_blocked_scan" 0|1 (default 0): how sdrx_process_u8 removes the DC bias.  0 = the
- *                 reference's sequentially rounded fp32 recurrence, bit for bit (~2.0 ms per
- *                 384 000-sample frame: two waves, each alone with its dependent chain, between a
- *                 parallel products and a parallel apply kernel).  1 = the same linear filter as a blocked
- *                 parallel scan (~15 us): the true IIR response.  The reference's recurrence
+ *                 reference's sequentially rounded fp32 recurrence, bit for bit (below).  1 = the same linear filter as a
+ *                 blocked parallel scan (~15 us): the true IIR response.  The reference's recurrence
  *                 wanders around that by up to ~3e-3 of the DC offset (its rounding errors are
  *                 correlated from step to step), so 1 is NOT within the 1e-5 parity tolerance
- *                 of the reference unless the offset is well below 1 LSB. */
+ *                 of the reference unless the offset is well below 1 LSB.
+ *   "dc_speculative" 1 (default) | 0: how the bit-exact recurrence is evaluated.  1 = blocks of 1024 samples as integer
+ *                 prefix sums of the mantissa, each block VERIFIED (binade, sign and the rounding of avept * (1 - 1e-6)
+ *                 unchanged through the block, no exact ties) and redone with the sequential operations where the
+ *                 verification fails: bit-exact by construction, ~0.1 ms per 384 000-sample frame with an offset in steady
+ *                 state, at worst the sequential time (sdrx_stats.dc_blocks / dc_fallback_blocks).  0 = the sequential
+ *                 recurrence for every sample (~2.0 ms per frame: two waves, each alone with its dependent chain): A/B switch. */
 int sdrx_set_option(sdrx_ctx *ctx, const char *name, int value);
 /* All of vfo::init for every node: NCO tables (oscillator.cpp:4-32), low-pass designs
  * (firfilter.cpp:64-119), Hilbert taps (dsp.cpp:184-217), zeroed filter state, buffers.
@@ -293,6 +297,8 @@ typedef struct sdrx_stats {
     int64_t frames;                      /* frames processed so far                          */
     int64_t mix_chunks_per_frame;        /* 1024-sample chunks the k_mix_decimate waves walk  */
                                          /*   per frame, warm-up chunks of segments included  */
+    int64_t dc_blocks;                   /* exact DC-bias removal (sdrx_process_u8 .. correct_dc): 1024-sample blocks of one */
+    int64_t dc_fallback_blocks;          /*   component walked so far / of those, redone with the sequential operations     */
 } sdrx_stats;
 int sdrx_get_stats(sdrx_ctx *ctx, sdrx_stats *out);
 /* Per-kernel GPU time from HIP events recorded on the launch stream.  enable=1 brackets every

@@ -462,6 +462,145 @@ __global__ __launch_bounds__(64) void k_dc_chain(const float *__restrict__ P, fl
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(junk)); // the last line prefetches have landed: the register is free again
 }
 
+// The SAME recurrence, bit for bit, a block of 1024 samples at a time in parallel: k_dc_chain_spec.
+//
+// What makes fl(fl(a keep) + p) sequential is its two roundings.  Write a = s m 2^e with the 24-bit mantissa 2^23 <= m < 2^24
+// (ulp = 2^e) and keep = 1 - 17 2^-24:
+//   fl(a keep) = s (m - r(m)) 2^e,   r(m) = floor(17 m / 2^24 + 1/2)     the product m (2^24 - 17) 2^(e-24) rounded to 24 bits; it
+//                                                                        stays in the binade for m >= 2^23 + 9 and is a tie only
+//                                                                        for m = 2^23.  r is one of 9 .. 17 and CONSTANT over runs
+//                                                                        of ~987 000 consecutive m, while a step moves m by
+//                                                                        |p| / ulp -- tens to a few hundred
+//   fl(u + p)  = s (m_u + q) 2^e,    q = s RN(p / 2^e)                   u and the result multiples of the same ulp as long as the
+//                                                                        sum stays in the binade; which way an exact tie of
+//                                                                        p / 2^e goes depends on the parity of m_u
+// So WHILE the binade, the sign and r stay what they are at the block's first sample and no p is an exact tie, the recurrence is
+// an integer prefix sum:  m_t = m_0 + sum_{i <= t} (q_i - r).  q_i comes out of ONE float addition that does the rounding for
+// us -- v = fl(C + p) with C = s 1.5 2^23 2^e has a's ulp, so the mantissa bits of v are those of C plus q_i (C's mantissa is even:
+// its ties go where an even m_u's would, and ties are excluded anyway) --, the tie test out of the exact residual p - (v - C).
+// One wave per component walks the frame block by block: lane l takes samples 16 l .. 16 l + 15 of the block (a serial prefix of
+// 16, then a 6-step DPP scan of the lane totals), every m_t of the block INCLUDING the last is checked against the run of m
+// over which r is constant (and >= 2^23 + 32: nothing may touch the binade's lower end, where fl(a keep) falls into the finer
+// grid below), and only a block that passes is taken; a block that does not -- r changes inside it, the binade or the sign does,
+// a tie, |a| < 2^-9 (start-up: p is no longer small against a) -- is redone with the rounded float operations themselves, one
+// dependent mul + add pair per sample: k_dc_chain's arithmetic, 1024 steps.  Verified blocks are bit-exact BY CONSTRUCTION, the
+// others by definition.  Steady state (|offset| >= 0.25 LSB): 0-10 % of the blocks fall back, depending on how close the offset
+// sits to one of r's thresholds (sdrx_stats.dc_blocks / dc_fallback_blocks).  Output as k_dc_chain's: A[c][j] = avept before
+// sample 16 j, for k_dc_apply.
+constexpr int kDcBlock = 64 * kRun; // samples per block: a lane's run is one stored estimate's 16 samples
+__device__ __forceinline__ int wave_inclusive_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+    return x;
+}
+__global__ __launch_bounds__(64) void k_dc_chain_spec(const float *__restrict__ P, float *__restrict__ A, int n_complex, int stride,
+                                                      float *__restrict__ state, unsigned long long *__restrict__ counters)
+{
+    const int c = blockIdx.x, lane = threadIdx.x; // component; lane
+    const float *p_c = P + (size_t)c * stride;
+    float *a_c = A + (size_t)c * (stride >> 4);
+    const float keep = 1.0f - 0.000001f;
+    float acc = state[c]; // (wave-uniform throughout)
+    const int nblk = (n_complex + kDcBlock - 1) / kDcBlock;
+    unsigned fallbacks = 0;
+    float p[kRun], pn[kRun];
+    auto load = [&](int b, float *dst) { // lane's 16 products of block b (the padding behind the frame is zero and never used)
+        const float4 *src = reinterpret_cast<const float4 *>(p_c + (size_t)b * kDcBlock + lane * kRun);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const v4f v = gldv4(src + i);
+            dst[4 * i] = v.x, dst[4 * i + 1] = v.y, dst[4 * i + 2] = v.z, dst[4 * i + 3] = v.w;
+        }
+    };
+    // one block: `p` holds the lane's products of block b, `pn` receives those of block b + 1 meanwhile
+    auto block = [&](int b, float *p, float *pn) {
+        if (b + 1 < nblk)
+            load(b + 1, pn);
+        const int nv = min(64, (n_complex - b * kDcBlock) >> 4); // lanes that hold samples (frames are multiples of 16)
+        const unsigned bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc));
+        const unsigned ex = (bits >> 23) & 255u, sign = bits & 0x80000000u;
+        const unsigned m0 = (bits & 0x7fffffu) | 0x800000u;
+        const unsigned r = (17u * m0 + (1u << 23)) >> 24;
+        // the run of m over which r(m) = r:  r 2^24 <= 17 m + 2^23 < (r + 1) 2^24, cut to the part of the binade the argument covers
+        const unsigned mlo = max(((r << 24) - (1u << 23) + 16u) / 17u, (1u << 23) + 32u);
+        const unsigned mhi = min((((r + 1u) << 24) - (1u << 23) + 16u) / 17u, 1u << 24);
+        const bool ctx_ok = ex >= 118u && ex < 255u && m0 >= mlo && m0 < mhi; // |a| >= 2^-9: |p| / ulp < 2^21
+        const unsigned cb = sign | (ex << 23) | 0x400000u;
+        const float C = __builtin_bit_cast(float, cb);                                   // s 1.5 2^23 ulp
+        const float half_ulp = __builtin_bit_cast(float, (ex >= 25u ? ex - 24u : 1u) << 23);
+        const int cbits = (int)cb + (int)r; // bits(v) - this = q - r in units of the MAGNITUDE's ulp
+        // (bits(v) - bits(C) is the change of the magnitude's mantissa: for a negative accumulator it is -RN(p / ulp), as it must be)
+        if (nv < 64 && lane >= nv) { // (the frame's last block) lanes behind the frame: a product that leaves m where it is, q = r
+            const float neutral = __builtin_bit_cast(float, sign | ((ex >= 23u ? ex - 23u : 0u) << 23)) * (float)r; // s r ulp
+#pragma unroll
+            for (int i = 0; i < kRun; ++i)
+                p[i] = neutral;
+        }
+        bool tie = false;
+        int pre[kRun];
+        int run = 0;
+#pragma unroll
+        for (int i = 0; i < kRun; ++i) {
+            const float v = C + p[i];
+            const float resid = p[i] - (v - C); // exact
+            tie |= fabsf(resid) == half_ulp;
+            run += __builtin_bit_cast(int, v) - cbits;
+            pre[i] = run;
+        }
+        const int incl = wave_inclusive_scan(run);
+        const int excl = incl - run;
+        // every m of the block -- before the lane's first sample and after each of its 16 -- inside [mlo, mhi)
+        const unsigned width = mhi - mlo;
+        const unsigned base = m0 - mlo + (unsigned)excl;
+        bool ok = base < width && !tie;
+#pragma unroll
+        for (int i = 0; i < kRun; ++i)
+            ok &= base + (unsigned)pre[i] < width;
+        const bool all_ok = ctx_ok && __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+        float start; // avept before this lane's first sample
+        if (all_ok) {
+            const unsigned hi = sign | ((ex - 1u) << 23); // + a mantissa with its leading one = the float
+            start = __builtin_bit_cast(float, hi + (m0 + (unsigned)excl));
+            const unsigned end_m = (unsigned)__builtin_amdgcn_readlane((int)(m0 + (unsigned)incl), 63);
+            acc = __builtin_bit_cast(float, hi + end_m);
+        } else {
+            // the rounded operations themselves, lane after lane: every lane runs the 16 steps on its own products from the
+            // uniform accumulator, lane l's result is the accumulator of the next round
+            ++fallbacks;
+            start = acc;
+            for (int l = 0; l < nv; ++l) {
+                float t = acc;
+                if (lane == l)
+                    start = acc;
+#pragma unroll
+                for (int i = 0; i < kRun; ++i)
+                    t = t * keep + p[i]; // -ffp-contract=off: v_mul_f32, v_add_f32
+                acc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), l));
+            }
+        }
+        if (lane < nv)
+            *(SDRX_AS1 float *)(a_c + (size_t)b * 64 + lane) = start;
+    };
+    load(0, p);
+    for (int b = 0; b < nblk; b += 2) { // (two blocks per round: the product registers swap roles instead of being copied)
+        block(b, p, pn);
+        if (b + 1 < nblk)
+            block(b + 1, pn, p);
+    }
+    if (lane == 0) {
+        state[c] = acc;
+        if (counters) {
+            atomicAdd(counters + 0, (unsigned long long)nblk);
+            atomicAdd(counters + 1, (unsigned long long)fallbacks);
+        }
+    }
+}
+
 // curr - avept in tile layout: one thread = the 16 samples behind one stored estimate = one lane's run of a tile
 __global__ __launch_bounds__(256) void k_dc_apply(const unsigned *__restrict__ bytes4, const float *__restrict__ A, float4 *__restrict__ tiled,
                                                   int n_complex, int stride)

@@ -31,7 +31,7 @@
 using namespace sdrx;
 
 static_assert(sizeof(sdrx_vfo_desc) == 56 && offsetof(sdrx_vfo_desc, topic) == 48, "sdrx_vfo_desc ABI layout");
-static_assert(sizeof(sdrx_stats) == 56, "sdrx_stats ABI layout");
+static_assert(sizeof(sdrx_stats) == 72, "sdrx_stats ABI layout");
 
 namespace {
 
@@ -111,7 +111,7 @@ struct sdrx_ctx {
     std::string err;
     std::vector<Node> nodes;
     bool finalized = false;
-    int opt_exact = 1, opt_prequant = 0, opt_segments = 0, opt_dc_blocked = 0, opt_pipeline = 0;
+    int opt_exact = 1, opt_prequant = 0, opt_segments = 0, opt_dc_blocked = 0, opt_pipeline = 0, opt_dc_speculative = 1;
     int opt_fuse = 1, opt_frame_pipeline = 1, opt_fuse_late = 1, opt_keep_streams = 0;
     // sdrx_set_tap / sdrx_add_tap: the fused late-decimation leaves that keep decimate[0] because they are taps (vfo::fftVFOSlot
     // sets emitFFT on EVERY VFO whose topic matches, vfo.cpp:492-509): node -> its buffers per frame parity and the first
@@ -162,6 +162,7 @@ struct sdrx_ctx {
     unsigned char *d_raw_u8[2] = {nullptr, nullptr}; // the same for dongle bytes
     float *d_dc_state = nullptr;   // DC-bias accumulator (exact: [2]; fast: [parity][2])
     float *d_dc_work = nullptr;    // exact DC-bias removal: products P[2][stride] and estimates A[2][stride] of one frame
+    unsigned long long *d_dc_counters = nullptr; // k_dc_chain_spec: [0] blocks walked, [1] blocks redone with the sequential operations
     int dc_work_stride = 0;
     double *d_dc_tab = nullptr;    // fast DC scan: powers of the decay + per-chunk sums behind them
     unsigned long long dc_frames = 0; // frames the fast scan has run on (its state ping-pongs)
@@ -552,6 +553,7 @@ void free_device_state(sdrx_ctx *c)
     dfree(c->d_raw_tiled);
     dfree(c->d_dc_state);
     dfree(c->d_dc_work);
+    dfree(c->d_dc_counters);
     c->dc_work_stride = 0;
     dfree(c->d_dc_tab);
     c->raw_cap = 0;
@@ -679,6 +681,8 @@ int sdrx_set_option(sdrx_ctx *c, const char *name, int value)
         c->opt_segments = value < 0 ? 0 : value;
     else if (!strcmp(name, "dc_blocked_scan"))
         c->opt_dc_blocked = value != 0;
+    else if (!strcmp(name, "dc_speculative"))
+        c->opt_dc_speculative = value != 0;
     else if (!strcmp(name, "pipeline"))
         c->opt_pipeline = value != 0;
     else if (!strcmp(name, "fuse"))
@@ -1628,7 +1632,15 @@ int enqueue_u8_device(sdrx_ctx *c, const void *dev_bytes, int n_complex, int cor
         Bracket b(c, c->stream, KIND_INGEST, 0);
         hipLaunchKernelGGL(k_dc_products, dim3((words + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const unsigned *>(dev_bytes), Pp,
                            n_complex, c->dc_work_stride);
-        hipLaunchKernelGGL(k_dc_chain, dim3(2), dim3(64), 0, c->stream, Pp, Ap, n_complex, c->dc_work_stride, c->d_dc_state);
+        if (c->opt_dc_speculative) {
+            if (!c->d_dc_counters) {
+                HIPCHK(c, hipMalloc(&c->d_dc_counters, 2 * sizeof(unsigned long long)));
+                HIPCHK(c, hipMemsetAsync(c->d_dc_counters, 0, 2 * sizeof(unsigned long long), c->stream));
+            }
+            hipLaunchKernelGGL(k_dc_chain_spec, dim3(2), dim3(64), 0, c->stream, Pp, Ap, n_complex, c->dc_work_stride, c->d_dc_state, c->d_dc_counters);
+        } else {
+            hipLaunchKernelGGL(k_dc_chain, dim3(2), dim3(64), 0, c->stream, Pp, Ap, n_complex, c->dc_work_stride, c->d_dc_state);
+        }
         hipLaunchKernelGGL(k_dc_apply, dim3((words + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const unsigned *>(dev_bytes), Ap,
                            reinterpret_cast<float4 *>(c->d_raw_tiled), n_complex, c->dc_work_stride);
         mode = kRawTiled;
@@ -2040,6 +2052,14 @@ int sdrx_get_stats(sdrx_ctx *c, sdrx_stats *s)
     s->device_bytes = (int64_t)(c->arena_bytes + 2 * c->pay_bytes + c->raw_cap * 10);
     s->frames = (int64_t)c->frame_no;
     s->mix_chunks_per_frame = c->mix_chunks;
+    if (c->d_dc_counters) { // (waits for what is queued: a measurement call)
+        unsigned long long h[2] = {0, 0};
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(h, c->d_dc_counters, sizeof h, hipMemcpyDeviceToHost));
+        s->dc_blocks = (int64_t)h[0];
+        s->dc_fallback_blocks = (int64_t)h[1];
+    }
     return SDRX_OK;
 }
 

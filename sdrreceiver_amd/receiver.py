@@ -31,7 +31,7 @@ class Receiver:
 
     def __init__(self, device: int = 0, exact: bool = True, keep_prequant: bool = False, segments: int = 0,
                  dc_blocked_scan: bool = False, pipeline: bool = False, fuse: bool = True, frame_pipeline: bool = True,
-                 fuse_late: bool = True, keep_streams: bool = False):
+                 fuse_late: bool = True, keep_streams: bool = False, dc_speculative: bool = True):
         self.L = _lib.lib()
         h = C.c_void_p()
         rc = self.L.sdrx_create(C.byref(h), int(device))
@@ -51,6 +51,7 @@ class Receiver:
         self._chk(self.L.sdrx_set_option(self.h, b"frame_pipeline", int(bool(frame_pipeline))))
         self._chk(self.L.sdrx_set_option(self.h, b"fuse_late", int(bool(fuse_late))))
         self._chk(self.L.sdrx_set_option(self.h, b"keep_streams", int(bool(keep_streams))))
+        self._chk(self.L.sdrx_set_option(self.h, b"dc_speculative", int(bool(dc_speculative))))
         self.finalized = False
 
     # -- plumbing -----------------------------------------------------------------

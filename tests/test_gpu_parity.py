@@ -840,8 +840,10 @@ def test_u8_ingest_and_dc_bias_on_device(Receiver, correct_dc):
     rx.close()
 
 
-def test_dc_bias_removal_on_frames_of_every_shape(Receiver):
-    """The exact DC-bias removal walks the frame in groups of 32 samples with its scalar prefetch two groups ahead and a
+@pytest.mark.parametrize("speculative", [True, False])
+def test_dc_bias_removal_on_frames_of_every_shape(Receiver, speculative):
+    """Both evaluations of the exact recurrence (option dc_speculative: verified 1024-sample blocks / every sample in turn).
+    The sequential one walks the frame in groups of 32 samples with its scalar prefetch two groups ahead and a
     line prefetch 16 groups ahead of that: frames of 16 m samples, m odd and even, from 1 024 to ~70 000 (a last group of 16
     samples; frames shorter than the prefetch distance), the accumulator carried over five frames: bit-exact against the
     oracle's sequential restatement of sdrj.cpp:277-283."""
@@ -856,7 +858,7 @@ def test_dc_bias_removal_on_frames_of_every_shape(Receiver):
                                  gain=tp._g(0.05), cstyle=1, samples_per_buffer=n))
         t.vfos.append(tp.VfoDesc(topic="IQ0", parent=-1, fs=4 * n, decimate_count=0, mixer_freq=-float(n // 5), demod_usb=False,
                                  cstyle=0, samples_per_buffer=n))
-        rx = Receiver.from_topology(t, exact=True)
+        rx = Receiver.from_topology(t, exact=True, dc_speculative=speculative)
         nodes, roots = ob.build_tree("port", t)
         state = np.zeros(2, np.float32)
         for f in range(5):
@@ -868,6 +870,85 @@ def test_dc_bias_removal_on_frames_of_every_shape(Receiver):
             ob.process_roots(roots, iq)
             assert np.array_equal(bits(rx.raw()), bits(iq.view(np.complex64))), (n, f, "raw frame after the DC-bias removal")
             _check_exact(rx, nodes, t, ("dc", n, f))
+        rx.close()
+
+
+DC_STREAMS = {  # (offset I, offset Q, noise sigma) in LSB
+    "offsets of the capture-like stream": (1.3, -0.7, 7.0),
+    "next to a binade boundary and a rounding threshold": (0.25, 4.94, 7.0),
+    "large, opposite signs": (100.0, -120.0, 10.0),
+    "no offset at all (the estimate wanders through zero)": (0.0, 0.02, 7.0),
+    "strong carriers": (1.3, -0.7, 50.0),
+}
+
+
+@pytest.mark.parametrize("stream", sorted(DC_STREAMS))
+def test_speculative_dc_chain_is_the_sequential_recurrence(Receiver, stream):
+    """k_dc_chain_spec evaluates avept = fl(fl(avept * (1 - 1e-6)) + fl(1e-6 * curr)) (sdrj.cpp:277-283) a block of 1 024 samples
+    at a time as an integer prefix sum of the mantissa, verifies the block and falls back to the rounded operations where the
+    verification fails.  12 frames of 384 000 samples from the zero start state (the estimate climbs through ~20 binades:
+    blocks that fall back and blocks that do not alternate), offsets that sit on a binade boundary / next to a threshold of
+    the rounding, both signs, an estimate that crosses zero: the DC-corrected frame bit for bit the oracle's, and identical
+    to the every-sample evaluation (dc_speculative=0).  The last frames of the benign streams run almost entirely in
+    verified blocks."""
+    di, dq, sigma = DC_STREAMS[stream]
+    n = 384000
+    t = tp.Topology(fs=1536000, frame=n, name="dcspec")
+    t.vfos.append(tp.VfoDesc(topic="M", parent=-1, fs=1536000, decimate_count=3, mixer_freq=-496000.0, demod_usb=False, cstyle=1,
+                             samples_per_buffer=n))
+    rx = Receiver.from_topology(t, exact=True)
+    rx0 = Receiver.from_topology(t, exact=True, dc_speculative=False)
+    rng = np.random.default_rng(100 + sorted(DC_STREAMS).index(stream))
+    state = np.zeros(2, np.float32)
+    prev = (0, 0)
+    for f in range(12):
+        z = rng.standard_normal(2 * n) * sigma
+        z[0::2] += di
+        z[1::2] += dq
+        b = np.clip(np.rint(z) + 127, 0, 255).astype(np.uint8)
+        rx.process_u8(b, correct_dc=True)
+        iq = ob.u8_to_float(b)
+        ob.dc_correct(iq, state)
+        assert np.array_equal(bits(rx.raw()), bits(iq.view(np.complex64))), (stream, f, "vs the oracle")
+        if f % 4 == 3:
+            rx0.process_u8(b, correct_dc=True)
+            assert np.array_equal(bits(rx0.raw()), bits(iq.view(np.complex64))), (stream, f, "every-sample evaluation vs the oracle")
+        else:
+            rx0.process_u8(b, correct_dc=True)
+        st = rx.stats()
+        blocks, fb = st["dc_blocks"] - prev[0], st["dc_fallback_blocks"] - prev[1]
+        prev = (st["dc_blocks"], st["dc_fallback_blocks"])
+        assert blocks == 2 * 375
+        if f == 11:
+            print(f"{stream}: frame 11 redid {fb} of {blocks} blocks sequentially; estimates {state}")
+            if stream in ("offsets of the capture-like stream", "large, opposite signs", "strong carriers"):
+                assert fb <= blocks // 10, (stream, fb)
+    rx.close()
+    rx0.close()
+
+
+def test_speculative_dc_chain_on_constant_and_extreme_bytes(Receiver):
+    """All-255, all-0, all-127 and alternating 0 / 255 bytes, frames that are not a whole number of blocks (480 000 = 468.75
+    blocks, 57 600): the accumulator runs up to +-128 through every binade on the way, `p` is one value (every block either
+    verifies or is an exact tie), the last block is partial."""
+    for n in (480000, 57600):
+        t = tp.Topology(fs=4 * n, frame=n, name=f"dcx{n}")
+        t.vfos.append(tp.VfoDesc(topic="M", parent=-1, fs=4 * n, decimate_count=2, mixer_freq=float(n // 7), demod_usb=False, cstyle=1,
+                                 samples_per_buffer=n))
+        rx = Receiver.from_topology(t, exact=True)
+        state = np.zeros(2, np.float32)
+        frames = []
+        for val in (255, 0, 127):
+            frames += [np.full(2 * n, val, np.uint8)] * 2
+        alt = np.zeros(2 * n, np.uint8)
+        alt[0::4] = 255
+        alt[1::4] = 255
+        frames += [alt, alt]
+        for f, b in enumerate(frames):
+            rx.process_u8(b, correct_dc=True)
+            iq = ob.u8_to_float(b)
+            ob.dc_correct(iq, state)
+            assert np.array_equal(bits(rx.raw()), bits(iq.view(np.complex64))), (n, f)
         rx.close()
 
 
