@@ -629,25 +629,42 @@ def main():
                "note": "host float/byte frame in, int16 payloads in host memory out, publish callbacks off; median of 3"}
         for kind in ("sync_pageable", "sync_pinned", "pipelined_pageable", "pipelined_pinned", "pipelined_u8"):
             abi[kind + "_ms"] = host_loop(kind)
-        # dongle bytes WITH the DC-bias removal of the shipped sdr_25E profile (correct_dc_bias=1, sdrj.cpp:271-286):
-        # the reference's sequentially rounded recurrence, bit for bit, is one wave walking the frame
-        u8 = (job.frames_np[0] + 127).astype(np.uint8)
-        for label, fn in (("u8_dc_sync_ms", lambda: rx.process_u8(u8, correct_dc=True)),):
-            fn()
-            barrier()
-            t1 = time.perf_counter()
-            for _k in range(4):
-                fn()
-            barrier()
-            abi[label] = round((time.perf_counter() - t1) / 4 * 1e3, 4)
-        rx.submit_u8(u8, correct_dc=True)
+        # dongle bytes WITH the DC-bias removal of the shipped sdr_25E profile (correct_dc_bias=1, sdrj.cpp:271-286), bit for bit
+        # the reference's sequentially rounded recurrence.  Input: the capture-like stream (sdrreceiver_amd/synth.py: noise,
+        # carriers, bursts and the ADC OFFSET the correction exists for), 8 frames in turn after 8 frames of settling -- the
+        # recurrence runs in verified 1024-sample blocks where it can (k_dc_chain_spec) and sample by sample where it cannot,
+        # and with NO offset at all (the zero-mean LCG frames of the other legs: the estimate wanders through zero, binade after
+        # binade) it mostly cannot: that worst case is `u8_dc_zero_offset_sync_ms` (~ the every-sample evaluation's 2.4 ms).
+        cap = synth.capture_like_u8(8, topo.frame, topo.fs) if topo.fs == 1536000 else None
+        cap = [cap[2 * topo.frame * f: 2 * topo.frame * (f + 1)] for f in range(8)] if cap is not None else [(job.frames_np[0] + 128).astype(np.uint8)]
+        for b_ in cap:
+            rx.process_u8(b_, correct_dc=True)
+        st0 = rx.stats()
+        barrier()
+        t1 = time.perf_counter()
+        for b_ in cap:
+            rx.process_u8(b_, correct_dc=True)
+        barrier()
+        abi["u8_dc_sync_ms"] = round((time.perf_counter() - t1) / len(cap) * 1e3, 4)
+        rx.submit_u8(cap[0], correct_dc=True)
         barrier_t = time.perf_counter()
-        for _k in range(1, 6):
-            rx.submit_u8(u8, correct_dc=True)
+        for b_ in cap[1:]:
+            rx.submit_u8(b_, correct_dc=True)
             rx.wait()
         rx.wait()
-        abi["u8_dc_pipelined_ms"] = round((time.perf_counter() - barrier_t) / 6 * 1e3, 4)
+        abi["u8_dc_pipelined_ms"] = round((time.perf_counter() - barrier_t) / len(cap) * 1e3, 4)
         abi["u8_dc_ms_per_frame"] = abi["u8_dc_pipelined_ms"]
+        st1 = rx.stats()
+        abi["u8_dc_blocks"] = {"walked": int(st1["dc_blocks"] - st0["dc_blocks"]), "redone_sequentially": int(st1["dc_fallback_blocks"] - st0["dc_fallback_blocks"]),
+                               "input": "capture-like stream (offsets +1.3 / -0.7 LSB), frames 8-23 of the run"}
+        u8z = (job.frames_np[0] + 127).astype(np.uint8)
+        rx.process_u8(u8z, correct_dc=True)
+        barrier()
+        t1 = time.perf_counter()
+        for _k in range(4):
+            rx.process_u8(u8z, correct_dc=True)
+        barrier()
+        abi["u8_dc_zero_offset_sync_ms"] = round((time.perf_counter() - t1) / 4 * 1e3, 4)
         rx.set_publish(True)
         t1 = time.perf_counter()
         for _k in range(4):

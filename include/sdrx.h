@@ -193,7 +193,9 @@ int sdrx_submit_device(sdrx_ctx *ctx, const void *dev_iq, int n_complex);
  * upload the frame once per main: run through `ctx` the frame `src` staged LAST (host floats or dongle bytes given
  * to sdrx_process* / sdrx_submit* of `src`; not after a DC-bias removal on the device) without another
  * host-to-device copy.  `ctx` waits for src's upload on the device.  src's frame buffers are per frame parity: the
- * shared frame stays valid until `src` stages the frame after next -- wait for it on `ctx` before that. */
+ * shared frame stays valid until `src` stages the frame after next -- wait for it on `ctx` before that.  `ctx` and `src`
+ * must be driven from one thread (the call touches both; contexts carry no locks -- like the reference, where every VFO
+ * runs on the one thread of sdrj::demodData). */
 int sdrx_submit_shared(sdrx_ctx *ctx, sdrx_ctx *src);
 int sdrx_process_shared(sdrx_ctx *ctx, sdrx_ctx *src); /* = sdrx_submit_shared + sdrx_wait */
 /* The same for a binding that cannot KNOW that two main VFOs were handed the same samples (host/qt/vfo_adapter.cpp: `class

@@ -468,26 +468,32 @@ __global__ __launch_bounds__(64) void k_dc_chain(const float *__restrict__ P, fl
 // (ulp = 2^e) and keep = 1 - 17 2^-24:
 //   fl(a keep) = s (m - r(m)) 2^e,   r(m) = floor(17 m / 2^24 + 1/2)     the product m (2^24 - 17) 2^(e-24) rounded to 24 bits; it
 //                                                                        stays in the binade for m >= 2^23 + 9 and is a tie only
-//                                                                        for m = 2^23.  r is one of 9 .. 17 and CONSTANT over runs
-//                                                                        of ~987 000 consecutive m, while a step moves m by
-//                                                                        |p| / ulp -- tens to a few hundred
+//                                                                        for m = 2^23.  r is one of 9 .. 17 and constant over
+//                                                                        runs of ~987 000 consecutive m; T = where it steps
 //   fl(u + p)  = s (m_u + q) 2^e,    q = s RN(p / 2^e)                   u and the result multiples of the same ulp as long as the
 //                                                                        sum stays in the binade; which way an exact tie of
 //                                                                        p / 2^e goes depends on the parity of m_u
-// So WHILE the binade, the sign and r stay what they are at the block's first sample and no p is an exact tie, the recurrence is
-// an integer prefix sum:  m_t = m_0 + sum_{i <= t} (q_i - r).  q_i comes out of ONE float addition that does the rounding for
-// us -- v = fl(C + p) with C = s 1.5 2^23 2^e has a's ulp, so the mantissa bits of v are those of C plus q_i (C's mantissa is even:
-// its ties go where an even m_u's would, and ties are excluded anyway) --, the tie test out of the exact residual p - (v - C).
-// One wave per component walks the frame block by block: lane l takes samples 16 l .. 16 l + 15 of the block (a serial prefix of
-// 16, then a 6-step DPP scan of the lane totals), every m_t of the block INCLUDING the last is checked against the run of m
-// over which r is constant (and >= 2^23 + 32: nothing may touch the binade's lower end, where fl(a keep) falls into the finer
-// grid below), and only a block that passes is taken; a block that does not -- r changes inside it, the binade or the sign does,
-// a tie, |a| < 2^-9 (start-up: p is no longer small against a) -- is redone with the rounded float operations themselves, one
-// dependent mul + add pair per sample: k_dc_chain's arithmetic, 1024 steps.  Verified blocks are bit-exact BY CONSTRUCTION, the
-// others by definition.  Steady state (|offset| >= 0.25 LSB): 0-10 % of the blocks fall back, depending on how close the offset
-// sits to one of r's thresholds (sdrx_stats.dc_blocks / dc_fallback_blocks).  Output as k_dc_chain's: A[c][j] = avept before
-// sample 16 j, for k_dc_apply.
+// So WHILE the binade and the sign stay what they are at the block's first sample and no p is an exact tie, the recurrence is
+// one in INTEGERS:  m' = m + q - r_lo - [m >= T]  around the threshold T of r nearest to the block's first m (r = r_lo below
+// it, r_lo + 1 from it on).  q comes out of ONE float addition that does the rounding for us -- v = fl(C + p) with C =
+// s 1.5 2^23 2^e has a's ulp, so the mantissa bits of v are those of C plus q (C's mantissa is even: its ties go where an even
+// m_u's would, and ties are excluded anyway) --, the tie test out of the exact residual p - (v - C).
+// (The reference's estimate LIVES at such a threshold: below T the decrement r_lo is smaller than the mean of q, above it
+// r_lo + 1 is larger, so m climbs to T and then hovers around it -- 1.2353 for an offset of 1.3 LSB, not 1.3.)
+// One wave per component walks the frame block by block; lane l owns samples 16 l .. 16 l + 15 of the block.  Every lane runs
+// the integer recurrence for its 16 samples from a SPECULATED start value; the lanes' totals are scanned (6 DPP steps) into
+// new start values; repeated until no start value changes -- then every lane started from the true value (lane 0 always does;
+// lane l does if all before it did) and its 16 steps are the recurrence itself.  The first guess -- r constant over the block
+// -- is already the answer unless some lane's run comes across T.  A converged block is then VERIFIED: every m it visited,
+// INCLUDING the last, inside [start of r_lo's run, end of (r_lo + 1)'s run) and >= 2^23 + 32 (nothing may touch the binade's
+// lower end, where fl(a keep) falls into the finer grid below), no exact tie.  A block that does not converge in kDcMaxIter
+// rounds or fails the verification -- the binade or the sign changes inside it, a tie, |a| < 2^-9 (start-up: p is no longer
+// small against a), an estimate PINNED to T by steps of an ulp or two (an offset many times the noise) -- is redone with the
+// rounded float operations themselves, one dependent mul + add pair per sample: k_dc_chain's arithmetic, 1024 steps.
+// Verified blocks are bit-exact BY CONSTRUCTION, the others by definition (sdrx_stats.dc_blocks / dc_fallback_blocks say how
+// many there were of each).  Output as k_dc_chain's: A[c][j] = avept before sample 16 j, for k_dc_apply.
 constexpr int kDcBlock = 64 * kRun; // samples per block: a lane's run is one stored estimate's 16 samples
+constexpr int kDcMaxIter = 6;       // rounds of "every lane from its speculated start value" before a block is given up
 __device__ __forceinline__ int wave_inclusive_scan(int x)
 {
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); // row_shr:1
@@ -524,50 +530,62 @@ __global__ __launch_bounds__(64) void k_dc_chain_spec(const float *__restrict__ 
         const int nv = min(64, (n_complex - b * kDcBlock) >> 4); // lanes that hold samples (frames are multiples of 16)
         const unsigned bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc));
         const unsigned ex = (bits >> 23) & 255u, sign = bits & 0x80000000u;
-        const unsigned m0 = (bits & 0x7fffffu) | 0x800000u;
-        const unsigned r = (17u * m0 + (1u << 23)) >> 24;
-        // the run of m over which r(m) = r:  r 2^24 <= 17 m + 2^23 < (r + 1) 2^24, cut to the part of the binade the argument covers
-        const unsigned mlo = max(((r << 24) - (1u << 23) + 16u) / 17u, (1u << 23) + 32u);
-        const unsigned mhi = min((((r + 1u) << 24) - (1u << 23) + 16u) / 17u, 1u << 24);
-        const bool ctx_ok = ex >= 118u && ex < 255u && m0 >= mlo && m0 < mhi; // |a| >= 2^-9: |p| / ulp < 2^21
+        const int m0 = (int)((bits & 0x7fffffu) | 0x800000u);
+        // r(m) = r for  r 2^24 <= 17 m + 2^23 < (r + 1) 2^24, i.e. from run_start(r) up to run_start(r + 1)
+        auto run_start = [](int r) { return (int)((((unsigned)r << 24) - (1u << 23) + 16u) / 17u); };
+        const int r0 = (int)((17u * (unsigned)m0 + (1u << 23)) >> 24);
+        const int lo0 = run_start(r0), hi0 = run_start(r0 + 1);
+        const bool near_lo = m0 - lo0 < hi0 - m0;
+        const int T = near_lo ? lo0 : hi0, rlo = near_lo ? r0 - 1 : r0;
+        const int lo = max(run_start(rlo), (1 << 23) + 32), hi = min(run_start(rlo + 2), 1 << 24);
+        const bool ctx_ok = ex >= 118u && ex < 255u && m0 >= lo && m0 < hi; // |a| >= 2^-9: |p| / ulp < 2^21
         const unsigned cb = sign | (ex << 23) | 0x400000u;
         const float C = __builtin_bit_cast(float, cb);                                   // s 1.5 2^23 ulp
         const float half_ulp = __builtin_bit_cast(float, (ex >= 25u ? ex - 24u : 1u) << 23);
-        const int cbits = (int)cb + (int)r; // bits(v) - this = q - r in units of the MAGNITUDE's ulp
-        // (bits(v) - bits(C) is the change of the magnitude's mantissa: for a negative accumulator it is -RN(p / ulp), as it must be)
-        if (nv < 64 && lane >= nv) { // (the frame's last block) lanes behind the frame: a product that leaves m where it is, q = r
-            const float neutral = __builtin_bit_cast(float, sign | ((ex >= 23u ? ex - 23u : 0u) << 23)) * (float)r; // s r ulp
-#pragma unroll
-            for (int i = 0; i < kRun; ++i)
-                p[i] = neutral;
-        }
+        // bits(v) - bits(C) = the change of the MAGNITUDE's mantissa (for a negative accumulator -RN(p / ulp), as it must be);
+        // e[i] = that - r_lo - 1, so that a step is  z' = z + e[i] + [z < 0]  for z = m - T
+        const int ebase = (int)cb + rlo + 1;
         bool tie = false;
-        int pre[kRun];
-        int run = 0;
+        int e[kRun], tot0 = 0;
 #pragma unroll
         for (int i = 0; i < kRun; ++i) {
             const float v = C + p[i];
             const float resid = p[i] - (v - C); // exact
             tie |= fabsf(resid) == half_ulp;
-            run += __builtin_bit_cast(int, v) - cbits;
-            pre[i] = run;
+            e[i] = __builtin_bit_cast(int, v) - ebase;
+            tot0 += e[i];
         }
-        const int incl = wave_inclusive_scan(run);
-        const int excl = incl - run;
-        // every m of the block -- before the lane's first sample and after each of its 16 -- inside [mlo, mhi)
-        const unsigned width = mhi - mlo;
-        const unsigned base = m0 - mlo + (unsigned)excl;
-        bool ok = base < width && !tie;
+        const bool mine = lane < nv;
+        tot0 = mine ? tot0 + kRun * (rlo + 1 - r0) : 0; // the lane's 16 steps with r = r0 throughout: the first guess
+        int zs = m0 - T + (wave_inclusive_scan(tot0) - tot0), zend = zs, zmin = zs, zmax = zs; // start value of this lane's run, minus T
+        bool converged = false;
+        for (int it = 0; it < kDcMaxIter && ctx_ok; ++it) {
+            int z = zs;
+            zmin = zmax = zs;
 #pragma unroll
-        for (int i = 0; i < kRun; ++i)
-            ok &= base + (unsigned)pre[i] < width;
-        const bool all_ok = ctx_ok && __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+            for (int i = 0; i < kRun; ++i) {
+                z = z + e[i] + (int)((unsigned)z >> 31);
+                zmin = min(zmin, z);
+                zmax = max(zmax, z);
+            }
+            zend = mine ? z : zs;
+            const int tot = zend - zs;
+            const int znew = m0 - T + (wave_inclusive_scan(tot) - tot);
+            const bool same = znew == zs;
+            zs = znew;
+            if (__builtin_amdgcn_ballot_w64(!same) == 0ull) {
+                converged = true;
+                break;
+            }
+        }
+        const bool ok = !mine || (!tie && zmin + T >= lo && zmax + T < hi);
+        const bool all_ok = converged && __builtin_amdgcn_ballot_w64(!ok) == 0ull;
         float start; // avept before this lane's first sample
         if (all_ok) {
-            const unsigned hi = sign | ((ex - 1u) << 23); // + a mantissa with its leading one = the float
-            start = __builtin_bit_cast(float, hi + (m0 + (unsigned)excl));
-            const unsigned end_m = (unsigned)__builtin_amdgcn_readlane((int)(m0 + (unsigned)incl), 63);
-            acc = __builtin_bit_cast(float, hi + end_m);
+            const unsigned hi_bits = sign | ((ex - 1u) << 23); // + a mantissa with its leading one = the float
+            start = __builtin_bit_cast(float, hi_bits + (unsigned)(zs + T));
+            const unsigned end_m = (unsigned)(__builtin_amdgcn_readlane(zend, 63) + T); // (lanes behind the frame pass their start value on)
+            acc = __builtin_bit_cast(float, hi_bits + end_m);
         } else {
             // the rounded operations themselves, lane after lane: every lane runs the 16 steps on its own products from the
             // uniform accumulator, lane l's result is the accumulator of the next round
@@ -583,7 +601,7 @@ __global__ __launch_bounds__(64) void k_dc_chain_spec(const float *__restrict__ 
                 acc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), l));
             }
         }
-        if (lane < nv)
+        if (mine)
             *(SDRX_AS1 float *)(a_c + (size_t)b * 64 + lane) = start;
     };
     load(0, p);

@@ -152,8 +152,14 @@ struct sdrx_ctx {
                                            //   be working on it: sdrx_submit_shared)
     hipEvent_t ev_staged[2] = {nullptr, nullptr}; // the host frame of parity p is complete on the device
     // other contexts that ran on this context's uploaded frame of parity p (sdrx_submit_shared): each left an event behind its
-    // kernels, and this context's next upload into that buffer waits for them (events owned, and reused, by this context)
-    std::vector<hipEvent_t> shared_readers[2], reader_pool;
+    // kernels, and this context's next upload into that buffer waits for them (events owned, and reused, by this context).
+    // No lock: `ctx` and `src` of a sharing call must be driven from ONE thread (sdrx.h).
+    struct SharedReader {
+        const sdrx_ctx *who; // (identity only: never dereferenced)
+        hipEvent_t ev;       // behind who's kernels on this context's frame of that parity; owned by THIS context
+        bool pending;        // recorded since this context last waited for it
+    };
+    std::vector<SharedReader> shared_readers[2]; // at most one entry per (reader, parity): re-recorded, never piled up
     float2 *d_raw_tiled = nullptr; // the raw frame in tile layout: input of the parent-less VFOs
     int last_raw = -1;             // how the last frame reached level 0 (kRaw*; -1: caller-owned device memory)
     bool late4 = false;            // k_late_decimate4 serves the late-decimation launch
@@ -652,9 +658,9 @@ int sdrx_destroy(sdrx_ctx *c)
     drain_events(c);
     for (hipEvent_t e : c->event_pool)
         (void)hipEventDestroy(e);
-    for (auto *v : {&c->reader_pool, &c->shared_readers[0], &c->shared_readers[1]})
-        for (hipEvent_t e : *v)
-            (void)hipEventDestroy(e);
+    for (auto *v : {&c->shared_readers[0], &c->shared_readers[1]})
+        for (const auto &r : *v)
+            (void)hipEventDestroy(r.ev);
     for (int p = 0; p < 2; ++p)
         for (hipEvent_t e : {c->ev_levels[p], c->ev_tail[p], c->ev_copied[p], c->ev_staged[p]})
             if (e)
@@ -1567,11 +1573,11 @@ int stage_host_frame(sdrx_ctx *c, const void *src, size_t bytes, void *dst_dev)
         c->h_in_bytes = (size_t)c->root_frame * sizeof(float2);
     }
     memcpy(c->h_in[p], src, bytes);
-    for (hipEvent_t e : c->shared_readers[p]) { // whoever shared frame f-2 of this buffer has read it before it is overwritten
-        HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
-        c->reader_pool.push_back(e);
-    }
-    c->shared_readers[p].clear();
+    for (auto &r : c->shared_readers[p]) // whoever shared frame f-2 of this buffer has read it before it is overwritten
+        if (r.pending) {
+            HIPCHK(c, hipStreamWaitEvent(c->stream, r.ev, 0));
+            r.pending = false;
+        }
     HIPCHK(c, hipMemcpyAsync(dst_dev, c->h_in[p], bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_staged[p], c->stream)); // (for a context that shares this frame: sdrx_submit_shared)
     return SDRX_OK;
@@ -1732,23 +1738,30 @@ static int submit_shared(sdrx_ctx *c, sdrx_ctx *src, const char *what, bool sync
         return rc;
     if (src->last_raw == kRawU8 && !c->root_direct)
         return fail(c, SDRX_EUNSUPPORTED, "%s: a wide level 0 (more than 4 parent-less VFOs) shares float frames only", what);
+    // src's NEXT upload into this buffer (its frame after next) must not overtake this context's kernels: an event behind
+    // them, which src's staging waits for.  One event per (reader, parity), acquired BEFORE anything is queued -- a failure
+    // here leaves no frame in flight -- and re-recorded for every shared frame (a source that never restages, or a reader
+    // fed through sdrx_process_device, does not pile events up).
+    sdrx_ctx::SharedReader *slot = nullptr;
+    for (auto &r : src->shared_readers[p])
+        if (r.who == c)
+            slot = &r;
+    if (!slot) {
+        hipEvent_t e = nullptr;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        src->shared_readers[p].push_back({c, e, false});
+        slot = &src->shared_readers[p].back();
+    }
     HIPCHK(c, hipStreamWaitEvent(c->stream, src->ev_staged[p], 0));
     c->last_raw = -1; // (not this context's buffer: sdrx_get_raw is served by `src`)
     const int src_raw = src->last_raw;
     rc = c->opt_exact ? enqueue_frame<true>(c, frame, src_raw, true) : enqueue_frame<false>(c, frame, src_raw, true);
     if (rc)
         return rc;
-    // src's NEXT upload into this buffer (its frame after next) must not overtake these kernels: an event behind them, which
-    // src's staging waits for.  (With the documented calling order -- wait for this frame on `c` first -- it has long fired.)
-    hipEvent_t e = nullptr;
-    if (!src->reader_pool.empty()) {
-        e = src->reader_pool.back();
-        src->reader_pool.pop_back();
-    } else {
-        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    HIPCHK(c, hipEventRecord(e, c->stream));
-    src->shared_readers[p].push_back(e);
+    if (hipEventRecord(slot->ev, c->stream) == hipSuccess)
+        slot->pending = true;
+    else
+        (void)hipStreamSynchronize(c->stream); // (the frame IS queued: order it the blunt way rather than report a failure)
     return SDRX_OK;
 }
 

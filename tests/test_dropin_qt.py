@@ -164,6 +164,24 @@ def test_adapter_processes_what_it_is_handed(mutate, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"SDRX_PIPELINE": "1"}, {"SDRX_DEVICES": "0,0"}])
+def test_two_vfos_with_one_topic_are_two_taps(env):
+    """vfo::fftVFOSlot sets emitFFT on EVERY VFO whose zmqTopic equals the selected string (vfo.cpp:492-509): an INI with one
+    topic on two VFOs has two spectrum taps.  Here both are /5 leaves whose decimation is fused into the mix wave -- they
+    keep decimate[0] only as taps (sdrx_add_tap gives each a buffer of its own) -- under different main VFOs, i.e. in two
+    trees of the adapter: the fftData log (frame, topic, length, hash of the samples) and the subscriber's stream are the
+    reference's, byte for byte."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdropin_ref.so")):
+        pytest.skip("oracle/_ref/libdropin_ref.so not built (make -C host/qt needs /root/reference)")
+    want = _raw("ref", "config4_12_shared_topic", 3, "SHARE", {})
+    assert sum(1 for l in want if "fft" in l) == 2 * 3  # two taps, three frames
+    got = _raw("sdrx", "config4_12_shared_topic", 3, "SHARE", env)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g == w
+
+
+@pytest.mark.gpu
 def test_adapter_on_random_trees():
     """The seeded random trees of tests/test_gpu_parity.py (1-3 levels, depths 0-4, USB and IQ leaves, late decimation,
     partial last chunks) behind the unmodified vfo.h: the reference's sources and the adapter, the same client, three

@@ -226,6 +226,36 @@ def test_config4_256_vfos_vs_cpu(Receiver, late):
     rx.close()
 
 
+def test_several_spectrum_taps_at_once(Receiver):
+    """vfo::fftVFOSlot sets emitFFT on every VFO whose topic equals the selected string (vfo.cpp:492-509), so several VFOs
+    can be taps at once: sdrx_add_tap adds to the selection, sdrx_set_tap replaces it.  All the /5 leaves of the 54W tree
+    as taps together (each keeps decimate[0] in a buffer of its own), then a smaller selection, then none: the tapped
+    streams are the oracle's bit for bit, the others answer SDRX_ENOSTREAM, payloads never change."""
+    from sdrreceiver_amd import _lib
+    from sdrreceiver_amd.receiver import SdrxError
+    topo = golden_topology("54w")
+    fused = [i for i, v in enumerate(topo.vfos) if v.late_decimate and v.decimate_count == 0 and v.parent >= 0]
+    assert len(fused) >= 4
+    rx = Receiver.from_topology(topo, exact=True)
+    nodes, roots = ob.build_tree("port", topo)
+    selections = [fused, fused[1:3], [fused[0], 0], [], fused[-2:]]
+    for f, iq in _frames(topo, len(selections), seed=29, tones=[(700000.0, 30.0)]):
+        rx.set_taps(selections[f])
+        rx.process(iq)
+        ob.process_roots(roots, iq)
+        for i in fused:
+            if i in selections[f]:
+                assert np.array_equal(bits(rx.stream(i)), bits(nodes[i].stream())), (f, i)
+            else:
+                with pytest.raises(SdrxError) as e:
+                    rx.stream(i)
+                assert e.value.code == _lib.SDRX_ENOSTREAM and rx.stream(i, missing_ok=True) is None
+        for i, v in enumerate(topo.vfos):
+            if not topo.children(i):
+                assert np.array_equal(rx.output(i), nodes[i].usb() if v.demod_usb else nodes[i].iq()), (f, i)
+    rx.close()
+
+
 def test_the_spectrum_tap_on_a_fused_late_decimation(Receiver):
     """fftVFOSlot on the 54W tree: a /5 leaf whose low-pass runs inside the mix wave keeps decimate[0] only while it is
     the tap (sdrx_set_tap), from the frame after the selection on; moving the tap moves the stream; every other stream
@@ -876,8 +906,10 @@ def test_dc_bias_removal_on_frames_of_every_shape(Receiver, speculative):
 DC_STREAMS = {  # (offset I, offset Q, noise sigma) in LSB
     "offsets of the capture-like stream": (1.3, -0.7, 7.0),
     "next to a binade boundary and a rounding threshold": (0.25, 4.94, 7.0),
-    "large, opposite signs": (100.0, -120.0, 10.0),
+    "large, opposite signs (one estimate pinned to its threshold)": (100.0, -120.0, 10.0),
+    "an offset ten times the noise (pinned)": (30.0, -2.0, 3.0),
     "no offset at all (the estimate wanders through zero)": (0.0, 0.02, 7.0),
+    "quiet front end": (1.3, -0.7, 2.0),
     "strong carriers": (1.3, -0.7, 50.0),
 }
 
@@ -885,12 +917,14 @@ DC_STREAMS = {  # (offset I, offset Q, noise sigma) in LSB
 @pytest.mark.parametrize("stream", sorted(DC_STREAMS))
 def test_speculative_dc_chain_is_the_sequential_recurrence(Receiver, stream):
     """k_dc_chain_spec evaluates avept = fl(fl(avept * (1 - 1e-6)) + fl(1e-6 * curr)) (sdrj.cpp:277-283) a block of 1 024 samples
-    at a time as an integer prefix sum of the mantissa, verifies the block and falls back to the rounded operations where the
-    verification fails.  12 frames of 384 000 samples from the zero start state (the estimate climbs through ~20 binades:
-    blocks that fall back and blocks that do not alternate), offsets that sit on a binade boundary / next to a threshold of
-    the rounding, both signs, an estimate that crosses zero: the DC-corrected frame bit for bit the oracle's, and identical
-    to the every-sample evaluation (dc_speculative=0).  The last frames of the benign streams run almost entirely in
-    verified blocks."""
+    at a time as an integer recurrence of the mantissa (every lane its 16 samples from a speculated start value, repeated
+    until the start values stand), verifies the block and falls back to the rounded operations where it does not converge
+    or the verification fails.  14 frames of 384 000 samples from the zero start state (the estimate climbs through ~20
+    binades: blocks that fall back and blocks that do not alternate; after ~3 s it has reached the threshold of the
+    rounding it then hovers around), offsets next to a binade boundary, both signs, an estimate that crosses zero, estimates
+    pinned to their threshold by steps of an ulp: the DC-corrected frame bit for bit the oracle's, and identical to the
+    every-sample evaluation (dc_speculative=0).  The last frames of the dongle-like streams run entirely in verified
+    blocks."""
     di, dq, sigma = DC_STREAMS[stream]
     n = 384000
     t = tp.Topology(fs=1536000, frame=n, name="dcspec")
@@ -901,7 +935,7 @@ def test_speculative_dc_chain_is_the_sequential_recurrence(Receiver, stream):
     rng = np.random.default_rng(100 + sorted(DC_STREAMS).index(stream))
     state = np.zeros(2, np.float32)
     prev = (0, 0)
-    for f in range(12):
+    for f in range(14):
         z = rng.standard_normal(2 * n) * sigma
         z[0::2] += di
         z[1::2] += dq
@@ -919,9 +953,9 @@ def test_speculative_dc_chain_is_the_sequential_recurrence(Receiver, stream):
         blocks, fb = st["dc_blocks"] - prev[0], st["dc_fallback_blocks"] - prev[1]
         prev = (st["dc_blocks"], st["dc_fallback_blocks"])
         assert blocks == 2 * 375
-        if f == 11:
-            print(f"{stream}: frame 11 redid {fb} of {blocks} blocks sequentially; estimates {state}")
-            if stream in ("offsets of the capture-like stream", "large, opposite signs", "strong carriers"):
+        if f == 13:
+            print(f"{stream}: frame 13 redid {fb} of {blocks} blocks sequentially; estimates {state}")
+            if stream in ("offsets of the capture-like stream", "quiet front end", "strong carriers"):
                 assert fb <= blocks // 10, (stream, fb)
     rx.close()
     rx0.close()

@@ -34,6 +34,13 @@ def topology(name):
         return tp.profile_25e()
     if name == "config4_12":
         return tp.config4(12)
+    if name == "config4_12_shared_topic":
+        # two /5 leaves (under different main VFOs) and one main VFO's IQ publisher carry ONE topic: fftVFOSlot(topic) sets
+        # emitFFT on every VFO whose zmqTopic equals the string (vfo.cpp:492-509), so all of them emit fftData
+        t = tp.config4(12)
+        t.vfos[4].topic = "SHARE"
+        t.vfos[9].topic = "SHARE"
+        return t
     if name.startswith("random:"):  # the seeded random trees of tests/test_gpu_parity.py
         import numpy as np
         sys.path.insert(0, os.path.join(ROOT, "tests"))
