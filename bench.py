@@ -208,7 +208,7 @@ class Verifier:
 def pmc_for(workload, exact):
     """profiles/current_pmc.json (tools/profile.sh + tools/pmc_summary.py): per-launch counter means of
     the committed PMC passes, if they were taken on this workload and arithmetic."""
-    for name in (f"pmc_{workload}.json", "current_pmc.json"):  # per-workload summaries next to the default one
+    for name in (f"pmc_{workload}.json" if exact else f"pmc_{workload}_tolerance.json", "current_pmc.json"):  # per-workload summaries next to the default one
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -692,6 +692,9 @@ def main():
             # float tolerance"; option exact = 0), each checked against the oracle at that tolerance
             for key, name in (("fast_config3", "config3"), ("fast_10k", "10k"), ("fast_config4", "config4")):
                 side[key] = side_reading(name, exact=False)
+        # BASELINE config 5's whole tree (65 536 sub VFOs) on this ONE GPU: the N = 1 origin of the strong-scaling curve the
+        # N > 1 lines carry as `config5_strong` (65 536 / N sub VFOs per GPU)
+        side["config5_64k_one_gpu"] = side_reading("64k")
 
     # fourth (N = 1): the Qt drop-in -- `class vfo` of the reference's unmodified vfo.h over the adapter
     # (host/qt/vfo_adapter.cpp), driven like sdrj::demodData drives it, transmitData / ZmqPublisher::publish included

@@ -184,6 +184,25 @@ __device__ __forceinline__ float2 gld2_once(const float2 *p)
     return make_float2(v.x, v.y);
 }
 __device__ __forceinline__ void gstv4(float4 *p, v4f v) { *(SDRX_AS1 v4f *)p = v; }
+// Stores that are ALWAYS issued, lanes that have nothing to store included: a buffer store whose offset lies beyond the
+// resource's num_records is dropped by the hardware, so "this lane does not store" is an offset, not a branch -- and a
+// store the compiler can see on every path is one it can COUNT: the s_waitcnt for loads issued in front of it then leaves
+// it outstanding (vmcnt(n) with the stores among the n) instead of waiting for its acknowledgement.
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr unsigned kNoStore = 0x7fffffffu; // a byte offset beyond every stream: the lane's store is dropped
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stream_rsrc(float2 *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffffe, 0x00020000); // raw buffer, no stride / swizzle, 32-bit data format
+}
+__device__ __forceinline__ void bst2(__amdgpu_buffer_rsrc_t r, unsigned byte_off, v2f v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, v4f v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), r, (int)byte_off, 0, 0);
+}
 
 // ------------------------------------------------------------------------------------ NCO
 // One step of the reference's table recurrence (oscillator.cpp:20-28): v *= rot (complex
@@ -331,6 +350,14 @@ __device__ __forceinline__ size_t tile_pos(int g)
 {
     const int c = g >> 10, r = g & 1023, ln = r >> 4, i = r & 15;
     return (size_t)c * 1024 + (i >> 1) * 128 + ln * 2 + (i & 1);
+}
+
+// A host frame from the library's pinned staging buffer (host memory, read over PCIe) into HBM: grid-stride copy of 16-byte
+// units.  A kernel instead of the DMA engine, so that the upload never queues behind a payload copy (sdrx.hip, stage_host_frame).
+__global__ __launch_bounds__(256) void k_upload(const uint4 *__restrict__ host, uint4 *__restrict__ dev, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        dev[i] = host[i];
 }
 
 // natural cf32 frame -> tile layout (host-fed / broadcast raw frames enter the pipeline here)
@@ -790,6 +817,8 @@ constexpr int kTransposeElems = kChunk + 2 * (kChunk >> 4); // 1152 float2
 __host__ __device__ constexpr int k1_lds_bytes(int d, bool need_transpose)
 {
     int stages = 8 * stage_offset(d < kRegStages ? kRegStages : d);
+    if (d == kRegStages && stages < 64 * 32)
+        stages = 64 * 32; // a d = 2 leaf parks its four outputs per lane here until the next chunk's loads are issued (HeldStores)
     int tr = need_transpose ? 8 * kTransposeElems : 0;
     return kCarryBytes + (stages > tr ? stages : tr);
 }
@@ -852,14 +881,24 @@ constexpr int kFixedDepth = 5; // 1.536 MS/s / 384 kS/s -> 48 / 12 kS/s: the dep
 // of a d = 5 leaf, whose last stage otherwise fills 32 of the 64 lanes; one carry hand-over and one set of phase fences per
 // two chunks).  Same arithmetic on the same values in the same order: an output does not know how many of its neighbours
 // were computed in the same pass.
+// A chunk's output stores, held back until the NEXT chunk's loads have been issued (mix_item's chunk loop): vmcnt counts a
+// wave's loads and stores in ONE in-order queue, so a wave that waits for loads issued behind its stores also waits for the
+// stores' acknowledgements -- measured on the tolerance-arithmetic kernel, the stores in front of the next chunk's loads cost
+// the launch 13 of its 63 us (profiles/README.md, round 5).  Stores issued behind the loads are never waited for.
+struct HeldStores {
+    v2f one;       // units == 1: the cf32 itself (last LDS stage of a d = 5 leaf)
+    int units = 0; // (everything below is wave-uniform: SGPRs) 0 nothing held; 1: `one` = output gbase + lane, held by the lanes
+                   //   jmin <= lane < nout; 2: z[0..3] of a d = 2 leaf, parked in the lane's 32 bytes of LDS, of the chunk at `base`
+    int gbase = 0, jmin = 0, nout = 0;
+    int base = 0, lv = 0;
+};
 template <bool EXACT, int S, int D, int M, int boff = 0>
-__device__ __forceinline__ void hb_stage_fixed1(v2f *__restrict__ lds, float2 *__restrict__ gout, int gbase, int jmin, int lane)
+__device__ __forceinline__ void hb_stage_fixed1(v2f *__restrict__ lds, HeldStores &held, int gbase, int jmin, int lane)
 {
     constexpr int cnt = M * (kChunk >> S), nout = cnt >> 1;
     v2f *A = lds + stage_offset(S);
     v2f *B = lds + stage_offset(S + 1); // (not touched by the last stage)
-    if constexpr (M == 2) // (the pass's LDS addresses are computed here, from this: hoisted out of the chunk loop one of them spills)
-        asm volatile("" : "+v"(lane));
+    asm volatile("" : "+v"(lane)); // (the pass's LDS addresses are computed here, from this: hoisted out of the chunk loop they spill)
     wave_sync(); // stage input (written by the previous phase) is visible
     if constexpr (nout >= 64) {
 #pragma unroll
@@ -867,19 +906,25 @@ __device__ __forceinline__ void hb_stage_fixed1(v2f *__restrict__ lds, float2 *_
             const int j = lane + 64 * it;
             const v2f *w = A + kCarry + 2 * j - 10;
             const v2f y = hb_dot2<EXACT>(w[0], w[2], w[4], w[5], w[6], w[8], w[10]);
-            if constexpr (S + 1 < D)
+            if constexpr (S + 1 < D) {
                 B[kCarry + boff + j] = y;
-            else if (j >= jmin)
-                gstv2_leaf(gout + (size_t)(gbase + j), y);
+            } else { // the leaf's stream: one output per lane, stored behind the next chunk's loads
+                static_assert(nout <= 64, "the last stage of a fixed-depth leaf has at most one output per lane");
+                held.one = y;
+                held.units = 1, held.gbase = gbase, held.jmin = jmin, held.nout = nout;
+            }
         }
     } else {
+        if constexpr (S + 1 == D)
+            held.units = 1, held.gbase = gbase, held.jmin = jmin, held.nout = nout;
         if (lane < nout) {
             const v2f *w = A + kCarry + 2 * lane - 10;
             const v2f y = hb_dot2<EXACT>(w[0], w[2], w[4], w[5], w[6], w[8], w[10]);
-            if constexpr (S + 1 < D)
+            if constexpr (S + 1 < D) {
                 B[kCarry + boff + lane] = y;
-            else if (lane >= jmin)
-                gstv2_leaf(gout + (size_t)(gbase + lane), y);
+            } else {
+                held.one = y;
+            }
         }
     }
     wave_sync(); // all window reads done before the carry is overwritten
@@ -892,11 +937,11 @@ __device__ __forceinline__ void hb_stage_fixed1(v2f *__restrict__ lds, float2 *_
 }
 // stages S .. D-1, each on M chunks' worth of input
 template <bool EXACT, int S, int D, int M>
-__device__ __forceinline__ void hb_stage_fixed(v2f *__restrict__ lds, float2 *__restrict__ gout, int gbase, int jmin, int lane)
+__device__ __forceinline__ void hb_stage_fixed(v2f *__restrict__ lds, HeldStores &held, int gbase, int jmin, int lane)
 {
-    hb_stage_fixed1<EXACT, S, D, M>(lds, gout, gbase, jmin, lane);
+    hb_stage_fixed1<EXACT, S, D, M>(lds, held, gbase, jmin, lane);
     if constexpr (S + 1 < D)
-        hb_stage_fixed<EXACT, S + 1, D, M>(lds, gout, gbase, jmin, lane);
+        hb_stage_fixed<EXACT, S + 1, D, M>(lds, held, gbase, jmin, lane);
 }
 #ifndef SDRX_PAIR_STAGES
 #define SDRX_PAIR_STAGES 1
@@ -923,9 +968,9 @@ __device__ __forceinline__ constexpr int halo_k(int q) { return q == 0 ? 10 : q 
 #endif
 // The body of one work item, run by ONE wave on LDS of its own (`smem`: k1_lds_bytes()); `level0`: the
 // item's VFO is fed by the raw frame (`raw`, `raw_mode`), otherwise by its parent's tile-layout stream.
-template <bool EXACT>
+template <bool EXACT, int DEPTH>
 __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K1Work W, unsigned long long frame_no,
-                                         const void *__restrict__ raw, int raw_mode, bool level0, unsigned char *smem, int lane)
+                                         const void *__restrict__ raw, int raw_mode, bool level0_arg, unsigned char *smem, int lane)
 {
     v2f *car0 = reinterpret_cast<v2f *>(smem);             // [8]
     v2f *car1 = car0 + 8;                                  // [8]
@@ -937,6 +982,13 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         const float2 *cp;
         int n_in, d, L, out_tiled;
     } D = {ldc(&Dp->cp), ldc(&Dp->n_in), ldc(&Dp->d), ldc(&Dp->L), ldc(&Dp->out_tiled)};
+    // DEPTH >= 0: the item is a LEAF with that many half-band stages below a parent (the shapes the time goes into: the
+    // reference's sub VFOs, 5 and 2 stages) -- depth, input form and output form are compile-time constants, every branch on
+    // them folds, and the chunk loop keeps only what that shape needs in registers.  DEPTH < 0: any VFO (run-time fields).
+    constexpr bool kShape = DEPTH >= 0;
+    const int dd = kShape ? DEPTH : D.d;
+    const bool level0 = kShape ? false : level0_arg;
+    const int otiled = kShape ? 0 : D.out_tiled;
     const v2f rot = {ldc(&Dp->rot_re), ldc(&Dp->rot_im)};
     const float4 *in = reinterpret_cast<const float4 *>(ldc(&Dp->in[par]));
     float2 *out = ldc(&Dp->out[par]);
@@ -950,10 +1002,10 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
     // warm-up chunks until every stage's window holds real samples again.
     if (lane < 8) {
         const int k = halo_k(lane);
-        car0[lane] = (from_state && D.d > 0) ? gldv2(hb_load + 0 * kHbHist + k - 1) : zero2;
-        car1[lane] = (from_state && D.d > 1) ? gldv2(hb_load + 1 * kHbHist + k - 1) : zero2;
+        car0[lane] = (from_state && dd > 0) ? gldv2(hb_load + 0 * kHbHist + k - 1) : zero2;
+        car1[lane] = (from_state && dd > 1) ? gldv2(hb_load + 1 * kHbHist + k - 1) : zero2;
     }
-    for (int s = kRegStages; s < D.d; ++s)
+    for (int s = kRegStages; s < dd; ++s)
         if (lane < kCarry) {
             const int k = kCarry - lane; // carry position `lane` is x[-k]
             lds[stage_offset(s) + lane] = (from_state && k <= kHbHist) ? gldv2(hb_load + s * kHbHist + k - 1) : zero2;
@@ -967,6 +1019,42 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
     // the lane's first 16-byte unit of the item as a 32-bit index (a frame has < 2^20 units): the loads below then take the
     // uniform stream pointer from SGPRs and one 32-bit VGPR offset instead of keeping a 64-bit pointer alive per lane
     const unsigned unit_item = (unsigned)(lane16 >> 6) * 512u + (unsigned)(lane16 & 63);
+    // this lane's NCO checkpoint for the chunk at `at`: cp[idx >> 4], idx = table position of the lane's first sample
+    auto cp_of = [&](int at) {
+        int ix = phase_frame + at; // both < L
+        ix -= ix >= D.L ? D.L : 0;
+        ix += lane * kRun;         // L >= kChunk (checked by sdrx_finalize)
+        ix -= ix >= D.L ? D.L : 0;
+        return D.cp + (ix >> 4);
+    };
+    // (the shaped bodies only: the any-VFO body has no register to spare -- it requests its checkpoint and stores its outputs
+    // where they arise)
+    v2f o_next = zero2;                   // the next chunk's checkpoint, requested a chunk ahead: the whole NCO hangs on these 8 bytes
+    if constexpr (kShape)
+        o_next = gldv2(cp_of(W.s_begin));
+    HeldStores held;                      // the previous chunk's output stores (issued behind this chunk's loads)
+    held.one = zero2;
+    auto flush_held = [&]() {
+        if constexpr (!kShape) { // (the any-VFO body stores at once: an ordinary conditional store)
+            if (held.units == 1 && lane >= held.jmin && lane < held.nout)
+                gstv2_leaf(out + (size_t)(held.gbase + lane), held.one);
+        } else if constexpr (DEPTH == 2) {
+            const __amdgpu_buffer_rsrc_t out_rsrc = stream_rsrc(out);
+            // (a lane reads back what it wrote itself: no fence needed; before the first chunk the LDS holds anything -- and
+            // units is 0, so nothing is stored)
+            const bool mine = held.units == 2 && (((held.base >> 4) + lane) << 4) >= first_out && lane <= held.lv;
+            const unsigned off = mine ? 8u * (unsigned)((held.base >> 2) + lane * 4) : kNoStore;
+            const v4f *park = reinterpret_cast<const v4f *>(lds) + 2 * lane;
+            bst4(out_rsrc, off, park[0]);
+            bst4(out_rsrc, off + 16u, park[1]);
+        } else {
+            const __amdgpu_buffer_rsrc_t out_rsrc = stream_rsrc(out);
+            // outputs below jmin belong to the warm-up of a segment that starts inside the frame
+            const bool mine = held.units == 1 && lane >= held.jmin && lane < held.nout;
+            bst2(out_rsrc, mine ? 8u * (unsigned)(held.gbase + lane) : kNoStore, held.one);
+        }
+        held.units = 0;
+    };
     int pair_base = -1; // >= 0: the stage-2 outputs of the chunk at this position wait in A_3 for the next chunk's (SDRX_PAIR_STAGES)
     for (int base = W.s_begin; base < W.s_end; base += kChunk) {
         const int valid = min(kChunk, D.n_in - base);
@@ -1025,11 +1113,14 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         // 2. NCO: regenerate table[idx .. idx+16) from the checkpoint before it, and mix
         //    (vfo.cpp:241: osc * sample).  The very first sample after start-up is multiplied
         //    by the LAST table entry (oscillator.cpp:30,39-50).
-        int idx = phase_frame + base; // both < L
-        idx -= idx >= D.L ? D.L : 0;
-        idx += lane * kRun;           // L >= kChunk (checked by sdrx_finalize)
-        idx -= idx >= D.L ? D.L : 0;
-        v2f o = gldv2(D.cp + (idx >> 4));
+        v2f o;
+        if constexpr (kShape) {
+            o = o_next; // (its load was issued a chunk ago)
+            o_next = gldv2(cp_of(base + kChunk < W.s_end ? base + kChunk : base)); // (always issued -- and therefore counted, like the stores)
+            flush_held(); // the previous chunk's outputs leave BEHIND this chunk's loads: nothing ever waits for them
+        } else {
+            o = gldv2(cp_of(base));
+        }
         const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
         bool replay = true;
         if constexpr (!EXACT) { // (wave-uniform) the chunk's 1024 table entries are settled ones and do not wrap
@@ -1050,9 +1141,9 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
             nco_mix_fast16(o, Dp->rk, x);
         }
 
-        if (D.d == 0) {
+        if (dd == 0) {
             // no decimation: decimate[0] is the mixed stream itself
-            if (D.out_tiled) {
+            if (otiled) {
                 if (emit_l && active) {
                     float4 *o4 = reinterpret_cast<float4 *>(out);
 #pragma unroll
@@ -1113,12 +1204,12 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
             for (int k = 1; k <= kHbHist; ++k)
                 gstv2(hb_save + 0 * kHbHist + k - 1, x[15 - k]);
 
-        if (D.d == 1) {
+        if (dd == 1) {
             if (emit_l && active) {
                 const int g = (base >> 1) + lane * 8;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const size_t pos = D.out_tiled ? tile_pos(g + 2 * i) : (size_t)(g + 2 * i);
+                    const size_t pos = otiled ? tile_pos(g + 2 * i) : (size_t)(g + 2 * i);
                     gstv4(reinterpret_cast<float4 *>(out + pos), cat2(y[2 * i], y[2 * i + 1]));
                 }
             }
@@ -1163,16 +1254,24 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         v2f z[4];
         hb_regs<EXACT, 4>(ext1, z);
 
-        if (D.d == 2) {
+        if (dd == 2) {
             if (emit_l && active) {
                 const int g = (base >> 2) + lane * 4;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    if (D.out_tiled)
+                    if (otiled)
                         gstv4(reinterpret_cast<float4 *>(out + tile_pos(g + 2 * i)), cat2(z[2 * i], z[2 * i + 1]));
-                    else
-                        gstv4_leaf(reinterpret_cast<float4 *>(out + (size_t)(g + 2 * i)), cat2(z[2 * i], z[2 * i + 1]));
                 }
+            }
+            if constexpr (kShape) { // its four outputs wait (in LDS) for the next chunk's loads to be on their way
+                v4f *park = reinterpret_cast<v4f *>(lds) + 2 * lane;
+                park[0] = cat2(z[0], z[1]);
+                park[1] = cat2(z[2], z[3]);
+                held.units = 2, held.base = base, held.lv = lv;
+            } else if (!otiled && emit_l && active) {
+                const int g = (base >> 2) + lane * 4;
+                gstv4_leaf(reinterpret_cast<float4 *>(out + (size_t)g), cat2(z[0], z[1]));
+                gstv4_leaf(reinterpret_cast<float4 *>(out + (size_t)(g + 2)), cat2(z[2], z[3]));
             }
             continue;
         }
@@ -1184,33 +1283,38 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
             *reinterpret_cast<v4f *>(A2 + 2) = cat2(z[2], z[3]);
         }
 #if SDRX_FIXED_STAGES
-        if (valid == kChunk && !save && !D.out_tiled && D.d == kFixedDepth) { // (uniform) a full chunk of a leaf, not the frame's last
+        if (kShape && valid == kChunk && !save && dd == kFixedDepth) { // (uniform) a full chunk, not the frame's last (the shaped body of a d = 5 leaf only)
 #if SDRX_PAIR_STAGES
             // stage 2 every chunk; stages 3 and 4 every second chunk on both chunks' stage-2 outputs -- when the NEXT chunk
             // of this item is such a chunk too (otherwise this one is finished alone: nothing pending ever meets another path)
             if (pair_base < 0 && base + kChunk < W.s_end && base + 2 * kChunk < D.n_in) {
-                hb_stage_fixed1<EXACT, 2, kFixedDepth, 1>(lds, out, 0, 0, lane);
+                hb_stage_fixed1<EXACT, 2, kFixedDepth, 1>(lds, held, 0, 0, lane);
                 pair_base = base;
                 continue;
             }
             if (pair_base >= 0) {
-                hb_stage_fixed1<EXACT, 2, kFixedDepth, 1, (kChunk >> 3)>(lds, out, 0, 0, lane);
+                hb_stage_fixed1<EXACT, 2, kFixedDepth, 1, (kChunk >> 3)>(lds, held, 0, 0, lane);
                 // outputs below jmin belong to the warm-up of a segment that starts inside the frame
-                hb_stage_fixed<EXACT, 3, kFixedDepth, 2>(lds, out, pair_base >> D.d, max(0, (first_out - pair_base) >> D.d), lane);
+                hb_stage_fixed<EXACT, 3, kFixedDepth, 2>(lds, held, pair_base >> dd, max(0, (first_out - pair_base) >> dd), lane);
                 pair_base = -1;
+                if constexpr (!kShape)
+                    flush_held();
                 continue;
             }
 #endif
-            const int jmin = max(0, (first_out - base) >> D.d), gbase = base >> D.d;
-            hb_stage_fixed<EXACT, 2, kFixedDepth, 1>(lds, out, gbase, jmin, lane);
+            const int jmin = max(0, (first_out - base) >> dd), gbase = base >> dd;
+            hb_stage_fixed<EXACT, 2, kFixedDepth, 1>(lds, held, gbase, jmin, lane);
+            if constexpr (!kShape)
+                flush_held();
             continue;
         }
 #endif
-        for (int s = kRegStages; s < D.d; ++s) {
-            hb_stage_lds<EXACT>(lds + stage_offset(s), lds + stage_offset(s + 1), out, base >> D.d, D.out_tiled != 0, s + 1 == D.d,
-                                max(0, (first_out - base) >> D.d), valid >> s, lane, save, hb_save + s * kHbHist);
+        for (int s = kRegStages; s < dd; ++s) {
+            hb_stage_lds<EXACT>(lds + stage_offset(s), lds + stage_offset(s + 1), out, base >> dd, otiled != 0, s + 1 == dd,
+                                max(0, (first_out - base) >> dd), valid >> s, lane, save, hb_save + s * kHbHist);
         }
     }
+    flush_held(); // the last chunk's outputs
 }
 
 // ------------------------------------------------------------------------------------ late_item
@@ -1265,6 +1369,18 @@ __device__ __forceinline__ void late_item(const K1Vfo *__restrict__ vfos, const 
     int wr_T = kRow - r0;
     const v2f *rd = buf + lane * kStride; // window sample u of this lane: rd[(kCarryRows + floor(u / kRow)) * kStride + u mod kRow]
     const int phase_frame = (int)((frame_no * (unsigned long long)D.n_in) % (unsigned long long)D.L);
+    // As in mix_item: the checkpoint the whole NCO hangs on is requested a chunk ahead (always issued: a load the compiler can
+    // count).  (Holding the chunk's outputs back behind the next chunk's loads, as mix_item's shaped bodies do, measured
+    // +2 % on config 4 here -- the parking in the window rows' padding and the three buffer stores cost more than the
+    // waits they avoid -- so this body stores where the outputs arise.)
+    auto cp_of = [&](int at) {
+        int ix = phase_frame + at; // both < L
+        ix -= ix >= D.L ? D.L : 0;
+        ix += lane * kRun;
+        ix -= ix >= D.L ? D.L : 0;
+        return D.cp + (ix >> 4);
+    };
+    v2f o_next = gldv2(cp_of(W.s_begin));
     int kb = W.s_begin / LD; // index of the first output of the chunk (s_begin is a multiple of L)
     for (int base = W.s_begin; base < W.s_end; base += G::kChunkLen, kb += G::kChunkLen / LD) {
         const int valid = min(G::kChunkLen, D.n_in - base);
@@ -1280,11 +1396,8 @@ __device__ __forceinline__ void late_item(const K1Vfo *__restrict__ vfos, const 
             x[2 * i + 1] = hi2(v);
         }
         // 2. NCO replay + mix, exactly as in mix_item (oscillator.cpp:20-28,39-50; vfo.cpp:241)
-        int idx = phase_frame + base; // both < L
-        idx -= idx >= D.L ? D.L : 0;
-        idx += lane * kRun;
-        idx -= idx >= D.L ? D.L : 0;
-        v2f o = gldv2(D.cp + (idx >> 4));
+        v2f o = o_next; // (its load was issued a chunk ago)
+        o_next = gldv2(cp_of(base + G::kChunkLen < W.s_end ? base + G::kChunkLen : base)); // (always issued, hence counted)
         const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
         bool replay = true;
         if constexpr (!EXACT) { // (wave-uniform) settled table entries, no wrap inside the chunk: the tolerance arithmetic's NCO
@@ -1313,7 +1426,7 @@ __device__ __forceinline__ void late_item(const K1Vfo *__restrict__ vfos, const 
         }
         // 3. to LDS, rows of 3 L samples
         wave_sync(); // the previous chunk's window reads and its carry rows are done
-        if (LD == 6) // (/6: 16 selects per chunk instead of 16 addresses kept across the loop -- there they spill; /5 keeps them)
+        if (LD == 6 || !EXACT) // (16 selects per chunk instead of 16 addresses kept across the loop -- there they spill; exact /5 keeps them)
             asm volatile("" : "+v"(wr_T));
         if (lane < G::kMixLanes) {
 #pragma unroll
@@ -1418,8 +1531,17 @@ __device__ __forceinline__ void run_item(const K1Vfo *__restrict__ vfos, const K
         late_item<EXACT, 5>(vfos, W, frame_no, smem, lane);
     else if (late == 6)
         late_item<EXACT, 6>(vfos, W, frame_no, smem, lane);
-    else
-        mix_item<EXACT>(vfos, W, frame_no, raw, raw_mode, level0, smem, lane);
+    else if ((level0 && raw_mode != kRawTiled) || ldc(&vfos[W.vfo].out_tiled))
+        mix_item<EXACT, -1>(vfos, W, frame_no, raw, raw_mode, level0, smem, lane);
+    else { // a leaf fed from a tile-layout stream: the two shapes of the reference's sub VFOs have bodies of their own
+        const int d = ldc(&vfos[W.vfo].d);
+        if (d == kFixedDepth)
+            mix_item<EXACT, kFixedDepth>(vfos, W, frame_no, raw, raw_mode, false, smem, lane);
+        else if (d == 2)
+            mix_item<EXACT, 2>(vfos, W, frame_no, raw, raw_mode, false, smem, lane);
+        else
+            mix_item<EXACT, -1>(vfos, W, frame_no, raw, raw_mode, level0, smem, lane);
+    }
 }
 
 // One wave per workgroup, one workgroup per K1Work.  LEVEL only gives the root launch and the sub

@@ -135,6 +135,7 @@ struct sdrx_ctx {
     // per-parity events below (measured on this runtime, tools/event_probe.hip: a record costs its
     // stream ~3-5 us, a wait on an event that completed long ago ~2.5 us, a tight hop ~11 us).
     hipStream_t own_stream = nullptr, stream = nullptr, tail_stream = nullptr, copy_stream = nullptr, copy_stream2 = nullptr;
+    bool upload_dma = false; // SDRX_UPLOAD_DMA=1: host frames go up with hipMemcpyAsync instead of k_upload (A/B switch)
     hipEvent_t ev_levels[2] = {nullptr, nullptr}; // levels of frame f done (recorded on `stream`)
     hipEvent_t ev_tail[2] = {nullptr, nullptr};   // tail of frame f done (recorded on the tail's stream)
     hipEvent_t ev_copied[2] = {nullptr, nullptr}; // payloads of frame f are in h_pay[f & 1]
@@ -624,6 +625,7 @@ int sdrx_create(sdrx_ctx **out, int device)
     c->stream = c->own_stream;
     bool ok = hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    c->upload_dma = getenv("SDRX_UPLOAD_DMA") && atoi(getenv("SDRX_UPLOAD_DMA")) != 0;
     // odd frames' payloads leave on a copy stream of their own: the next copy's set-up then overlaps the
     // current copy's tail (measured through the ABI on config 3: 0.296 vs 0.306 ms per frame;
     // SDRX_TWO_COPY_STREAMS=0 for A/B runs)
@@ -1578,7 +1580,19 @@ int stage_host_frame(sdrx_ctx *c, const void *src, size_t bytes, void *dst_dev)
             HIPCHK(c, hipStreamWaitEvent(c->stream, r.ev, 0));
             r.pending = false;
         }
-    HIPCHK(c, hipMemcpyAsync(dst_dev, c->h_in[p], bytes, hipMemcpyHostToDevice, c->stream));
+    // The frame goes up by a KERNEL that reads the pinned staging buffer over PCIe (k_upload), not by the DMA engine: the
+    // payload copy of the frame before -- a DMA copy queued behind an event -- holds its engine's in-order queue from the
+    // moment it is queued until it has run, and an upload queued behind it waited for it: the kernels of frame f+1 started
+    // when the payload copy of frame f ended, and the pipelined interface overlapped nothing (traced on the dongle-byte path:
+    // profiles/README.md, round 5).  SDRX_UPLOAD_DMA=1 restores hipMemcpyAsync (A/B).
+    if (c->upload_dma) {
+        HIPCHK(c, hipMemcpyAsync(dst_dev, c->h_in[p], bytes, hipMemcpyHostToDevice, c->stream));
+    } else {
+        const size_t n16 = (bytes + 15) / 16; // (both buffers are whole 16-byte units long: frames are multiples of 16 samples)
+        const int blocks = (int)std::min<size_t>((n16 + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_upload, dim3(blocks), dim3(256), 0, c->stream, reinterpret_cast<const uint4 *>(c->h_in[p]),
+                           reinterpret_cast<uint4 *>(dst_dev), n16);
+    }
     HIPCHK(c, hipEventRecord(c->ev_staged[p], c->stream)); // (for a context that shares this frame: sdrx_submit_shared)
     return SDRX_OK;
 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/ab_build.sh <name> "<EXTRA flags>" -- an experiment build of libsdrx.so into sdrreceiver_amd/csrc/ab/<name>.so.
-# The LDS-DMA prefetch (-DSDRX_GLDS=1|2: bit-exact, slower -- profiles/README.md rounds 3 and 4) and the phase ablations
+# The phase ablations of mix_item
 # (-DSDRX_ABL_LOAD/NCO/MIX/CARRY/ST0/ST1/LDS/STORE/CONFLICT: WRONG results by design, the phase-cost study) are no longer
 # part of the product's kernels.hip: tools/ablation.patch puts them back into a scratch copy of the sources, which this
 # script builds.  (The patch applies to the kernels.hip of the commit that introduced it: `git log tools/ablation.patch`.)
@@ -11,6 +11,6 @@ SCR=$ROOT/sdrreceiver_amd/csrc/ab/src_$NAME
 rm -rf "$SCR"; mkdir -p "$SCR/sdrreceiver_amd/csrc" "$SCR/include"
 cp "$ROOT"/include/sdrx.h "$SCR/include/"
 cp "$ROOT"/sdrreceiver_amd/csrc/{Makefile,*.hip,*.h} "$SCR/sdrreceiver_amd/csrc/"
-case "$EXTRA" in *SDRX_GLDS*|*SDRX_ABL_*) (cd "$SCR" && patch -p1 < "$ROOT/tools/ablation.patch") ;; esac
+case "$EXTRA" in *SDRX_ABL_*) (cd "$SCR" && patch -p1 < "$ROOT/tools/ablation.patch") ;; esac
 make -C "$SCR/sdrreceiver_amd/csrc" OUT="$ROOT/sdrreceiver_amd/csrc/ab/$NAME.so" EXTRA="$EXTRA"
 echo "built sdrreceiver_amd/csrc/ab/$NAME.so  (SDRX_LIB=<that path> loads it)"
