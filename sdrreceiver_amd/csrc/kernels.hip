@@ -352,12 +352,19 @@ __device__ __forceinline__ size_t tile_pos(int g)
     return (size_t)c * 1024 + (i >> 1) * 128 + ln * 2 + (i & 1);
 }
 
-// A host frame from the library's pinned staging buffer (host memory, read over PCIe) into HBM: grid-stride copy of 16-byte
-// units.  A kernel instead of the DMA engine, so that the upload never queues behind a payload copy (sdrx.hip, stage_host_frame).
-__global__ __launch_bounds__(256) void k_upload(const uint4 *__restrict__ host, uint4 *__restrict__ dev, size_t n16)
+// 16-byte units from one buffer to another, either of which may be pinned HOST memory reached over PCIe: the payloads' way
+// out (sdrx.hip, enqueue_frame).  Grid-stride with four units per thread in flight; the launch decides how much of the chip it
+// may occupy -- a PCIe-bound copy needs bytes in flight, not CUs.
+__global__ __launch_bounds__(256) void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
 {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
-        dev[i] = host[i];
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride)
+        dst[i] = src[i];
 }
 
 // natural cf32 frame -> tile layout (host-fed / broadcast raw frames enter the pipeline here)

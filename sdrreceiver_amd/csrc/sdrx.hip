@@ -135,7 +135,9 @@ struct sdrx_ctx {
     // per-parity events below (measured on this runtime, tools/event_probe.hip: a record costs its
     // stream ~3-5 us, a wait on an event that completed long ago ~2.5 us, a tight hop ~11 us).
     hipStream_t own_stream = nullptr, stream = nullptr, tail_stream = nullptr, copy_stream = nullptr, copy_stream2 = nullptr;
-    bool upload_dma = false; // SDRX_UPLOAD_DMA=1: host frames go up with hipMemcpyAsync instead of k_upload (A/B switch)
+    bool upload_kernel = false; // SDRX_UPLOAD_KERNEL=1: host frames go up with k_copy16 instead of hipMemcpyAsync (A/B switch; slower)
+    int download_blocks = 64;   // workgroups of the payload copy kernel (SDRX_DOWNLOAD_BLOCKS; 0: always hipMemcpyAsync) ...
+    bool long_frame = false;    // ... which carries the payloads of frames whose kernels outlast the copy (the DC-bias recurrence)
     hipEvent_t ev_levels[2] = {nullptr, nullptr}; // levels of frame f done (recorded on `stream`)
     hipEvent_t ev_tail[2] = {nullptr, nullptr};   // tail of frame f done (recorded on the tail's stream)
     hipEvent_t ev_copied[2] = {nullptr, nullptr}; // payloads of frame f are in h_pay[f & 1]
@@ -383,7 +385,20 @@ int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode, bool egress)
     if (egress) {
         hipStream_t cs = (p && c->copy_stream2) ? c->copy_stream2 : c->copy_stream;
         HIPCHK(c, hipStreamWaitEvent(cs, c->ev_tail[p], 0));
-        HIPCHK(c, hipMemcpyAsync(c->h_pay[p], c->d_pay[p], c->pay_bytes, hipMemcpyDeviceToHost, cs));
+        // How the payloads leave (measured, traced: profiles/README.md round 5).  hipMemcpyAsync moves a device-to-host copy with a
+        // copy KERNEL of the runtime's own (__amd_rocclr_copyBuffer), ~280 us for config 3's 15 MB at PCIe speed; the kernels of
+        // the next frame run beside it when they are short (config 3 from host floats: 0.30 ms per pipelined frame = the copy),
+        // but a frame that starts with the DC-bias recurrence (0.45 ms of kernels) did not start before that copy had ended --
+        // pipelined 0.85 ms per frame against 0.84 synchronous.  A copy kernel of our own on 64 workgroups behaves the other way
+        // round (0.79 ms with the recurrence, 0.41 without): each path gets the copy it is faster with.  SDRX_DOWNLOAD_BLOCKS=0:
+        // hipMemcpyAsync always; = n: n workgroups.
+        if (c->download_blocks > 0 && c->long_frame) {
+            const size_t n16 = (c->pay_bytes + 15) / 16; // (both buffers are allocated in whole 16-byte units)
+            hipLaunchKernelGGL(k_copy16, dim3(c->download_blocks), dim3(256), 0, cs, reinterpret_cast<const uint4 *>(c->d_pay[p]),
+                               reinterpret_cast<uint4 *>(c->h_pay[p]), n16);
+        } else {
+            HIPCHK(c, hipMemcpyAsync(c->h_pay[p], c->d_pay[p], c->pay_bytes, hipMemcpyDeviceToHost, cs));
+        }
         HIPCHK(c, hipEventRecord(c->ev_copied[p], cs));
         c->in_flight++;
     }
@@ -625,7 +640,9 @@ int sdrx_create(sdrx_ctx **out, int device)
     c->stream = c->own_stream;
     bool ok = hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
-    c->upload_dma = getenv("SDRX_UPLOAD_DMA") && atoi(getenv("SDRX_UPLOAD_DMA")) != 0;
+    c->upload_kernel = getenv("SDRX_UPLOAD_KERNEL") && atoi(getenv("SDRX_UPLOAD_KERNEL")) != 0;
+    if (getenv("SDRX_DOWNLOAD_BLOCKS"))
+        c->download_blocks = std::max(0, std::min(4096, atoi(getenv("SDRX_DOWNLOAD_BLOCKS"))));
     // odd frames' payloads leave on a copy stream of their own: the next copy's set-up then overlaps the
     // current copy's tail (measured through the ABI on config 3: 0.296 vs 0.306 ms per frame;
     // SDRX_TWO_COPY_STREAMS=0 for A/B runs)
@@ -1256,9 +1273,9 @@ int allocate_and_upload(sdrx_ctx *c, Built &B)
     HIPCHK(c, hipMemsetAsync(c->arena, 0, c->arena_bytes, c->stream));
     c->pay_bytes = std::max<size_t>(B.pay, 64);
     for (int p = 0; p < 2; ++p) {
-        HIPCHK(c, hipMalloc(&c->d_pay[p], c->pay_bytes));
+        HIPCHK(c, hipMalloc(&c->d_pay[p], align_up(c->pay_bytes, 16))); // (whole 16-byte units: k_copy16)
         HIPCHK(c, hipMemsetAsync(c->d_pay[p], 0, c->pay_bytes, c->stream));
-        HIPCHK(c, hipHostMalloc(&c->h_pay[p], c->pay_bytes, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc(&c->h_pay[p], align_up(c->pay_bytes, 16), hipHostMallocDefault));
         memset(c->h_pay[p], 0, c->pay_bytes);
     }
     {
@@ -1580,17 +1597,14 @@ int stage_host_frame(sdrx_ctx *c, const void *src, size_t bytes, void *dst_dev)
             HIPCHK(c, hipStreamWaitEvent(c->stream, r.ev, 0));
             r.pending = false;
         }
-    // The frame goes up by a KERNEL that reads the pinned staging buffer over PCIe (k_upload), not by the DMA engine: the
-    // payload copy of the frame before -- a DMA copy queued behind an event -- holds its engine's in-order queue from the
-    // moment it is queued until it has run, and an upload queued behind it waited for it: the kernels of frame f+1 started
-    // when the payload copy of frame f ended, and the pipelined interface overlapped nothing (traced on the dongle-byte path:
-    // profiles/README.md, round 5).  SDRX_UPLOAD_DMA=1 restores hipMemcpyAsync (A/B).
-    if (c->upload_dma) {
+    // (the runtime moves host-to-device copies with the DMA engine: concurrent with kernels.  SDRX_UPLOAD_KERNEL=1: a copy kernel
+    // reading the pinned buffer over PCIe instead -- measured slower, 0.353 vs 0.302 ms per pipelined frame on config 3: it sits
+    // in the compute stream's way)
+    if (!c->upload_kernel) {
         HIPCHK(c, hipMemcpyAsync(dst_dev, c->h_in[p], bytes, hipMemcpyHostToDevice, c->stream));
     } else {
         const size_t n16 = (bytes + 15) / 16; // (both buffers are whole 16-byte units long: frames are multiples of 16 samples)
-        const int blocks = (int)std::min<size_t>((n16 + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_upload, dim3(blocks), dim3(256), 0, c->stream, reinterpret_cast<const uint4 *>(c->h_in[p]),
+        hipLaunchKernelGGL(k_copy16, dim3(64), dim3(256), 0, c->stream, reinterpret_cast<const uint4 *>(c->h_in[p]),
                            reinterpret_cast<uint4 *>(dst_dev), n16);
     }
     HIPCHK(c, hipEventRecord(c->ev_staged[p], c->stream)); // (for a context that shares this frame: sdrx_submit_shared)
@@ -1675,7 +1689,9 @@ int enqueue_u8_device(sdrx_ctx *c, const void *dev_bytes, int n_complex, int cor
                            c->d_dc_tab, sums);
         mode = kRawTiled;
     }
+    c->long_frame = correct_dc && !c->opt_dc_blocked;
     const int rc = c->opt_exact ? enqueue_frame<true>(c, dev_bytes, mode, egress) : enqueue_frame<false>(c, dev_bytes, mode, egress);
+    c->long_frame = false;
     if (rc == SDRX_OK)
         c->last_raw = mode;
     return rc;

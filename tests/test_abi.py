@@ -53,3 +53,13 @@ def test_product_never_touches_the_oracle():
                     txt = open(os.path.join(dirpath, f), errors="replace").read()
                     assert "liborc" not in txt and "libsdrref" not in txt and "import oracle" not in txt \
                         and "from oracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_compiled_kernels_use_no_scratch_memory():
+    """`make asm` + tools/check_asm.py: every kernel of the gfx950 build at 0 bytes of scratch (a spill reload in a chunk loop
+    is a vector-memory operation behind an s_waitcnt), and k_dc_chain without an SGPR spill next to its scalar prefetch
+    (ADVICE r4).  hipcc cross-compiles without a GPU."""
+    import subprocess
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "sdrreceiver_amd", "csrc"), "asm"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "ISA check ok" in r.stdout

@@ -31,19 +31,15 @@ EDITS = [
                 asm volatile("" : "+v"(v));
 #endif
 """, 1),
-    ("""        v2f o = gldv2(D.cp + (idx >> 4));
-        const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
-        bool replay = true;
-        if constexpr (!EXACT) { // (wave-uniform) the chunk's 1024 table entries are settled ones and do not wrap""",
+    ("""            o_next = gldv2(cp_of(base + kChunk < W.s_end ? base + kChunk : base)); // (always issued -- and therefore counted, like the stores)
+""",
      """#ifndef SDRX_ABL_CP
-        v2f o = gldv2(D.cp + (idx >> 4));
+            o_next = gldv2(cp_of(base + kChunk < W.s_end ? base + kChunk : base)); // (always issued -- and therefore counted, like the stores)
 #else
-        v2f o = {0.9f + 1e-6f * idx, 0.1f}; // ablation: no checkpoint load
-        asm volatile("" : "+v"(o));
+            o_next = v2f{0.9f + 1e-6f * base, 0.1f}; // ablation: no checkpoint load
+            asm volatile("" : "+v"(o_next));
 #endif
-        const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
-        bool replay = true;
-        if constexpr (!EXACT) { // (wave-uniform) the chunk's 1024 table entries are settled ones and do not wrap""", 1),
+""", 1),
     ("""                o = nco_step_pk(o, rot);
                 v2f m = o;
                 if (i == 0 && first_ever)
@@ -54,7 +50,7 @@ EDITS = [
             nco_mix_fast16(o, Dp->rk, x);
         }
 
-        if (D.d == 0) {""",
+        if (dd == 0) {""",
      """#ifndef SDRX_ABL_NCO
                 o = nco_step_pk(o, rot);
 #else
@@ -79,7 +75,7 @@ EDITS = [
 #endif
         }
 
-        if (D.d == 0) {""", 1),
+        if (dd == 0) {""", 1),
     ("""        wave_sync(); // car0/car1 of the previous chunk (or the initial state) are visible
         {
             const v4f *c4 = reinterpret_cast<const v4f *>(car0); // broadcast reads""",

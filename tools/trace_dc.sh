@@ -8,11 +8,12 @@ python3 - <<PY
 import csv, glob
 ev = []
 for r in csv.DictReader(open(glob.glob("$OUT/*kernel_trace.csv")[0])):
-    if "sdrx::k_" in r["Kernel_Name"] and "nco_init" not in r["Kernel_Name"]:
-        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("sdrx::")[1].split("(")[0][:26]))
+    if "nco_init" not in r["Kernel_Name"]:  # (every kernel: the runtime's own copy kernels too)
+        n = r["Kernel_Name"]
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), (n.split("sdrx::")[1] if "sdrx::" in n else n).split("(")[0][:26] + " q" + r.get("Queue_Id", "?")))
 for f in glob.glob("$OUT/*memory_copy_trace.csv"):
     for r in csv.DictReader(open(f)):
-        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", r.get("Name", ""))[:20] ))
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", r.get("Name", ""))[12:34]))
 ev.sort()
 last = ev[-60:]
 t0 = last[0][0]
