@@ -1538,13 +1538,14 @@ __device__ __forceinline__ void run_item(const K1Vfo *__restrict__ vfos, const K
         late_item<EXACT, 5>(vfos, W, frame_no, smem, lane);
     else if (late == 6)
         late_item<EXACT, 6>(vfos, W, frame_no, smem, lane);
-    else if ((level0 && raw_mode != kRawTiled) || ldc(&vfos[W.vfo].out_tiled))
-        mix_item<EXACT, -1>(vfos, W, frame_no, raw, raw_mode, level0, smem, lane);
-    else { // a leaf fed from a tile-layout stream: the two shapes of the reference's sub VFOs have bodies of their own
+    else {
+        // a leaf fed from a tile-layout stream: the two shapes of the reference's sub VFOs have bodies of their own (0: any VFO)
+        const bool leaf_on_tiles = !(level0 && raw_mode != kRawTiled) && !ldc(&vfos[W.vfo].out_tiled);
         const int d = ldc(&vfos[W.vfo].d);
-        if (d == kFixedDepth)
+        const int shape = leaf_on_tiles && d == kFixedDepth ? kFixedDepth : leaf_on_tiles && d == 2 ? 2 : 0;
+        if (shape == kFixedDepth)
             mix_item<EXACT, kFixedDepth>(vfos, W, frame_no, raw, raw_mode, false, smem, lane);
-        else if (d == 2)
+        else if (shape == 2)
             mix_item<EXACT, 2>(vfos, W, frame_no, raw, raw_mode, false, smem, lane);
         else
             mix_item<EXACT, -1>(vfos, W, frame_no, raw, raw_mode, level0, smem, lane);

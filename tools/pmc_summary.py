@@ -171,7 +171,7 @@ def main():
     res = {"source": os.path.relpath(d), "git_sha": sha, "build_id": build_id, "workload": workload, "exact": exact, "kernels": {},
            "inst_mix": {"k_mix_decimate, d=5 sub VFO, per 1024-sample chunk (source count, packed = 1)": INST_MIX_D5 if exact else INST_MIX_D5_TOLERANCE,
                         "sum": sum((INST_MIX_D5 if exact else INST_MIX_D5_TOLERANCE).values()),
-                        "isa_check": "tools/inst_mix.py: the static v_pk_mul/add/fma_f32 and DPP counts of kernels.s == the source count (d = 5 leaf: 146/87.5/32/32 executed per chunk)"},
+                        "isa_check": "tools/inst_mix.py: the static v_pk_mul/add/fma_f32 and DPP counts of kernels.s == the source count of the bodies compiled into the kernel (d = 5 leaf: 146/87.5/32/32 executed per chunk)"},
            "note": "per-launch medians; hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE correction); every derived "
                    "figure takes numerator, cycles and duration from ONE pass (tools/pmc_summary.py)"}
     kernels = sorted({k for p in passes for k in p})
