@@ -969,6 +969,132 @@ __device__ __forceinline__ void hb_regs(const v2f *ext, v2f *y)
 // halo slot q (0..7) <-> distance k back from the lane's first sample: -10,-8,-6,-5,-4,-3,-2,-1
 __device__ __forceinline__ constexpr int halo_k(int q) { return q == 0 ? 10 : q == 1 ? 8 : q == 2 ? 6 : 8 - q; }
 
+// ---- the pieces of a chunk that mix_item and late_item share ---------------------------------------------------------------
+// The lane's 16 consecutive samples of a raw (natural-order) frame: cf32 as the caller handed it -- each lane reads its own
+// 128 contiguous bytes: uncoalesced across the wave, but a level of 2-3 main VFOs is latency bound and this saves the layout
+// pass over the raw frame -- or dongle bytes, floats[b] = b - 127 (jonti/sdr.cpp:43-49), 32 bytes per lane.
+__device__ __forceinline__ void load_run_raw(const void *__restrict__ raw, int raw_mode, int p16, bool active, v2f *x)
+{
+    if (raw_mode == kRawF32) {
+        const float4 *nat = reinterpret_cast<const float4 *>(raw) + (size_t)p16 * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+            const v4f v = active ? gldv4(nat + i) : z4;
+            x[2 * i] = lo2(v);
+            x[2 * i + 1] = hi2(v);
+        }
+    } else {
+        const v4u *nat = reinterpret_cast<const v4u *>(raw) + (size_t)p16 * 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const v4u z4 = {0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu}; // 127 -> 0.0f
+            const v4u q = active ? gldv4u(nat + h) : z4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned w = q[k];
+                const v2f a = {(float)((int)(w & 255u) - 127), (float)((int)((w >> 8) & 255u) - 127)};
+                const v2f b = {(float)((int)((w >> 16) & 255u) - 127), (float)((int)(w >> 24) - 127)};
+                x[8 * h + 2 * k] = a;
+                x[8 * h + 2 * k + 1] = b;
+            }
+        }
+    }
+}
+// The same out of a tile-layout stream: 8 coalesced 16-byte loads, unit (i2, lane) of the tile at `src`.
+__device__ __forceinline__ void load_run_tile(const float4 *__restrict__ src, v2f *x)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const v4f v = gldv4(src + 64 * i); // tile_unit(c, i, l) = tile_unit(c, 0, l) + 64 i
+        x[2 * i] = lo2(v);
+        x[2 * i + 1] = hi2(v);
+    }
+}
+// NCO + mixer on the lane's run (oscillator.cpp:20-28,39-50; vfo.cpp:241): regenerate table[idx .. idx + 16) from the
+// checkpoint `o` before it -- the exact recurrence, or in the tolerance arithmetic rotations of the checkpoint where the
+// chunk's `span` table entries from position i0 on are settled ones and do not wrap -- and multiply.  The very first sample
+// after start-up is multiplied by the LAST table entry (`last`: oscillator.cpp:30,39-50).
+template <bool EXACT>
+__device__ __forceinline__ void nco_mix(v2f o, v2f rot, const float2 *__restrict__ rk, const float2 *__restrict__ last, bool first_ever, int i0,
+                                        int span, int L, v2f *x)
+{
+    bool replay = true;
+    if constexpr (!EXACT) // (wave-uniform)
+        replay = i0 < kNcoSettle || i0 + span > L;
+    if (replay) {
+#pragma unroll
+        for (int i = 0; i < kRun; ++i) {
+            o = nco_step_pk(o, rot);
+            v2f m = o;
+            if (i == 0 && first_ever)
+                m = gldv2(last);
+            x[i] = cmul(m, x[i]);
+        }
+    } else {
+        nco_mix_fast16(o, rk, x);
+    }
+}
+// Stage 0's halo: ext0[0..9] = x[-10..-1] = the previous lane's x[6, 8, 10 .. 15] (one whole-wave DPP shift each); lane 0 takes
+// the previous chunk's lane 63 from the 8-entry LDS row car0, which lane 63 then refills for the next chunk.
+__device__ __forceinline__ void halo_stage0(v2f *car0, v2f *ext0, int lane)
+{
+    const v2f zero2 = {0.f, 0.f};
+    const v2f *x = ext0 + 10;
+    wave_sync(); // car0 of the previous chunk (or the initial state) is visible
+    {
+        const v4f *c4 = reinterpret_cast<const v4f *>(car0); // broadcast reads
+        const v4f q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
+        ext0[0] = shr1(lo2(q0), x[6]);   // x[-10]
+        ext0[2] = shr1(hi2(q0), x[8]);   // x[-8]
+        ext0[4] = shr1(lo2(q1), x[10]);  // x[-6]
+        ext0[5] = shr1(hi2(q1), x[11]);  // x[-5]
+        ext0[6] = shr1(lo2(q2), x[12]);  // x[-4]
+        ext0[7] = shr1(hi2(q2), x[13]);  // x[-3]
+        ext0[8] = shr1(lo2(q3), x[14]);  // x[-2]
+        ext0[9] = shr1(hi2(q3), x[15]);  // x[-1]
+        ext0[1] = ext0[3] = zero2;       // x[-9], x[-7]: never read
+    }
+    wave_sync(); // every lane holds its halo: lane 63 may now leave ITS tail for the next chunk
+    if (lane == 63) {
+        v4f *c4 = reinterpret_cast<v4f *>(car0);
+        c4[0] = cat2(x[6], x[8]);
+        c4[1] = cat2(x[10], x[11]);
+        c4[2] = cat2(x[12], x[13]);
+        c4[3] = cat2(x[14], x[15]);
+    }
+}
+// Stage 1's: y[-8, -6, -5, -4, -3, -2, -1] = the previous lane's y[0, 2 .. 7], y[-10] = the lane before that one's y[6] (a second
+// shift of the shifted y[6]); lanes 63 and 62 refill car1.
+__device__ __forceinline__ void halo_stage1(v2f *car1, v2f *ext1, int lane)
+{
+    const v2f zero2 = {0.f, 0.f};
+    const v2f *y = ext1 + 10;
+    {
+        const v4f *c4 = reinterpret_cast<const v4f *>(car1);
+        const v4f q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
+        ext1[2] = shr1(hi2(q0), y[0]);  // y[-8]
+        ext1[4] = shr1(lo2(q1), y[2]);  // y[-6]
+        ext1[5] = shr1(hi2(q1), y[3]);  // y[-5]
+        ext1[6] = shr1(lo2(q2), y[4]);  // y[-4]
+        ext1[7] = shr1(hi2(q2), y[5]);  // y[-3]
+        ext1[8] = shr1(lo2(q3), y[6]);  // y[-2]
+        ext1[9] = shr1(hi2(q3), y[7]);  // y[-1]
+        ext1[0] = shr1(lo2(q0), ext1[8]); // y[-10]
+        ext1[1] = ext1[3] = zero2;
+    }
+    wave_sync(); // every lane has read car1
+    if (lane == 63) {
+        car1[1] = y[0]; // slot 1 (y[-8]); slot 0 comes from lane 62
+        v4f *d4 = reinterpret_cast<v4f *>(car1);
+        d4[1] = cat2(y[2], y[3]);
+        d4[2] = cat2(y[4], y[5]);
+        d4[3] = cat2(y[6], y[7]);
+    }
+    if (lane == 62)
+        car1[0] = y[6];
+}
+
 // Fused NCO + mixer + half-band cascade.
 #ifndef SDRX_K1_MIN_WAVES
 #define SDRX_K1_MIN_WAVES 5 // waves per SIMD the register allocator must leave room for
@@ -1075,51 +1201,16 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         // 1. this lane's run of 16 consecutive samples: 8 coalesced 16-byte loads
         v2f ext0[10 + kRun]; // ext0[10 + t] = x[t]; ext0[0..9] = halo x[-10..-1]
         v2f *x = ext0 + 10;
-        if (level0 && raw_mode == kRawF32) {
-            // the caller's frame as it is (natural order): each lane reads its own 128 contiguous
-            // bytes.  Uncoalesced across the wave, but a level of 2-3 main VFOs is latency bound
-            // and this saves the layout pass over the raw frame.
-            const float4 *nat = reinterpret_cast<const float4 *>(raw) + (size_t)p16 * 8;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const v4f z4 = {0.f, 0.f, 0.f, 0.f};
-                const v4f v = active ? gldv4(nat + i) : z4;
-                x[2 * i] = lo2(v);
-                x[2 * i + 1] = hi2(v);
-            }
-        } else if (level0 && raw_mode == kRawU8) {
-            // dongle bytes: floats[b] = b - 127 (jonti/sdr.cpp:43-49), 32 bytes per lane
-            const v4u *nat = reinterpret_cast<const v4u *>(raw) + (size_t)p16 * 2;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const v4u z4 = {0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu}; // 127 -> 0.0f
-                const v4u q = active ? gldv4u(nat + h) : z4;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned w = q[k];
-                    const v2f a = {(float)((int)(w & 255u) - 127), (float)((int)((w >> 8) & 255u) - 127)};
-                    const v2f b = {(float)((int)((w >> 16) & 255u) - 127), (float)((int)(w >> 24) - 127)};
-                    x[8 * h + 2 * k] = a;
-                    x[8 * h + 2 * k + 1] = b;
-                }
-            }
+        if (level0 && raw_mode != kRawTiled) {
+            load_run_raw(raw, raw_mode, p16, active, x);
         } else {
-            // The lane's position inside its tile is the same in every chunk of the item (the walk
-            // advances by exactly one tile per chunk): src_item is computed once, a chunk adds 512
-            // units.  A shifted walk straddles two tiles; its idle lanes in the frame's last chunk may
-            // read the (zero) tile behind the last one, which every tile-layout buffer has.
-            const float4 *src = in + (unit_item + (unsigned)((base - W.s_begin) >> 10) * 512u);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const v4f v = gldv4(src + 64 * i); // tile_unit(c, i, l) = tile_unit(c, 0, l) + 64 i
-                x[2 * i] = lo2(v);
-                x[2 * i + 1] = hi2(v);
-            }
+            // The lane's position inside its tile is the same in every chunk of the item (the walk advances by exactly one tile
+            // per chunk): unit_item is computed once, a chunk adds 512 units.  A shifted walk straddles two tiles; its idle lanes
+            // in the frame's last chunk may read the (zero) tile behind the last one, which every tile-layout buffer has.
+            load_run_tile(in + (unit_item + (unsigned)((base - W.s_begin) >> 10) * 512u), x);
         }
 
-        // 2. NCO: regenerate table[idx .. idx+16) from the checkpoint before it, and mix
-        //    (vfo.cpp:241: osc * sample).  The very first sample after start-up is multiplied
-        //    by the LAST table entry (oscillator.cpp:30,39-50).
+        // 2. NCO and mixer (nco_mix).  The shaped bodies have this chunk's checkpoint already and request the next one.
         v2f o;
         if constexpr (kShape) {
             o = o_next; // (its load was issued a chunk ago)
@@ -1128,24 +1219,10 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         } else {
             o = gldv2(cp_of(base));
         }
-        const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
-        bool replay = true;
-        if constexpr (!EXACT) { // (wave-uniform) the chunk's 1024 table entries are settled ones and do not wrap
+        {
             int i0 = phase_frame + base;
             i0 -= i0 >= D.L ? D.L : 0;
-            replay = i0 < kNcoSettle || i0 + kChunk > D.L;
-        }
-        if (replay) {
-#pragma unroll
-            for (int i = 0; i < kRun; ++i) {
-                o = nco_step_pk(o, rot);
-                v2f m = o;
-                if (i == 0 && first_ever)
-                    m = gldv2(D.cp + (D.L >> 4));
-                x[i] = cmul(m, x[i]);
-            }
-        } else {
-            nco_mix_fast16(o, Dp->rk, x);
+            nco_mix<EXACT>(o, rot, Dp->rk, D.cp + (D.L >> 4), frame_no == 0 && base == 0 && lane == 0, i0, kChunk, D.L, x);
         }
 
         if (dd == 0) {
@@ -1179,30 +1256,8 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
             continue;
         }
 
-        // 3. stage 0 in registers.  Halo = the previous lane's x[6,8,10,11,12,13,14,15]
-        //    (one whole-wave DPP shift each); lane 0 takes the previous chunk's lane 63 from LDS.
-        wave_sync(); // car0/car1 of the previous chunk (or the initial state) are visible
-        {
-            const v4f *c4 = reinterpret_cast<const v4f *>(car0); // broadcast reads
-            const v4f q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
-            ext0[0] = shr1(lo2(q0), x[6]);   // x[-10]
-            ext0[2] = shr1(hi2(q0), x[8]);   // x[-8]
-            ext0[4] = shr1(lo2(q1), x[10]);  // x[-6]
-            ext0[5] = shr1(hi2(q1), x[11]);  // x[-5]
-            ext0[6] = shr1(lo2(q2), x[12]);  // x[-4]
-            ext0[7] = shr1(hi2(q2), x[13]);  // x[-3]
-            ext0[8] = shr1(lo2(q3), x[14]);  // x[-2]
-            ext0[9] = shr1(hi2(q3), x[15]);  // x[-1]
-            ext0[1] = ext0[3] = zero2;       // x[-9], x[-7]: never read
-        }
-        wave_sync(); // every lane holds its halo: lane 63 may now leave ITS tail for the next chunk
-        if (lane == 63) {
-            v4f *c4 = reinterpret_cast<v4f *>(car0);
-            c4[0] = cat2(x[6], x[8]);
-            c4[1] = cat2(x[10], x[11]);
-            c4[2] = cat2(x[12], x[13]);
-            c4[3] = cat2(x[14], x[15]);
-        }
+        // 3. stage 0 in registers
+        halo_stage0(car0, ext0, lane);
         v2f ext1[10 + 8]; // ext1[10 + t] = y[t] (stage-0 outputs of this lane), ext1[0..9] halo
         v2f *y = ext1 + 10;
         hb_regs<EXACT, 8>(ext0, y);
@@ -1223,31 +1278,8 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
             continue;
         }
 
-        // 4. stage 1 in registers.  Halo y[-8,-6,-5,-4,-3,-2,-1] = previous lane's y[0,2..7],
-        //    y[-10] = the lane before that one's y[6] (a second shift of the shifted y[6]).
-        {
-            const v4f *c4 = reinterpret_cast<const v4f *>(car1);
-            const v4f q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
-            ext1[2] = shr1(hi2(q0), y[0]);  // y[-8]
-            ext1[4] = shr1(lo2(q1), y[2]);  // y[-6]
-            ext1[5] = shr1(hi2(q1), y[3]);  // y[-5]
-            ext1[6] = shr1(lo2(q2), y[4]);  // y[-4]
-            ext1[7] = shr1(hi2(q2), y[5]);  // y[-3]
-            ext1[8] = shr1(lo2(q3), y[6]);  // y[-2]
-            ext1[9] = shr1(hi2(q3), y[7]);  // y[-1]
-            ext1[0] = shr1(lo2(q0), ext1[8]); // y[-10]
-            ext1[1] = ext1[3] = zero2;
-        }
-        wave_sync(); // every lane has read car1
-        if (lane == 63) {
-            car1[1] = y[0]; // slot 1 (y[-8]); slot 0 comes from lane 62
-            v4f *d4 = reinterpret_cast<v4f *>(car1);
-            d4[1] = cat2(y[2], y[3]);
-            d4[2] = cat2(y[4], y[5]);
-            d4[3] = cat2(y[6], y[7]);
-        }
-        if (lane == 62)
-            car1[0] = y[6];
+        // 4. stage 1 in registers
+        halo_stage1(car1, ext1, lane);
         if (save) { // next frame's stage-1 history: y[size1-1-k]
             if (lane == lv)
 #pragma unroll
@@ -1396,33 +1428,15 @@ __device__ __forceinline__ void late_item(const K1Vfo *__restrict__ vfos, const 
         const unsigned run = (unsigned)(base >> 4) + (unsigned)lane;
         const float4 *src = in + ((run >> 6) * 512u + (run & 63u));
         v2f x[kRun];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const v4f v = gldv4(src + 64 * i);
-            x[2 * i] = lo2(v);
-            x[2 * i + 1] = hi2(v);
-        }
-        // 2. NCO replay + mix, exactly as in mix_item (oscillator.cpp:20-28,39-50; vfo.cpp:241)
-        v2f o = o_next; // (its load was issued a chunk ago)
+        load_run_tile(src, x);
+        // 2. NCO and mixer, exactly as in mix_item
+        const v2f o = o_next; // (its load was issued a chunk ago)
         o_next = gldv2(cp_of(base + G::kChunkLen < W.s_end ? base + G::kChunkLen : base)); // (always issued, hence counted)
-        const bool first_ever = frame_no == 0 && base == 0 && lane == 0;
-        bool replay = true;
-        if constexpr (!EXACT) { // (wave-uniform) settled table entries, no wrap inside the chunk: the tolerance arithmetic's NCO
+        {
             int i0 = phase_frame + base;
             i0 -= i0 >= D.L ? D.L : 0;
-            replay = i0 < kNcoSettle || i0 + kChunk > D.L; // (the lanes past the chunk replay entries nobody uses: up to 64 x 16)
-        }
-        if (replay) {
-#pragma unroll
-            for (int i = 0; i < kRun; ++i) {
-                o = nco_step_pk(o, rot);
-                v2f m = o;
-                if (i == 0 && first_ever)
-                    m = gldv2(D.cp + (D.L >> 4));
-                x[i] = cmul(m, x[i]);
-            }
-        } else {
-            nco_mix_fast16(o, Dp->rk, x);
+            // (kChunk, not kChunkLen: the lanes past the chunk replay entries nobody uses -- up to 64 x 16 of them must not wrap either)
+            nco_mix<EXACT>(o, rot, Dp->rk, D.cp + (D.L >> 4), frame_no == 0 && base == 0 && lane == 0, i0, kChunk, D.L, x);
         }
         if (tap && lane < G::kMixLanes && 16 * lane < valid && base + 16 * lane >= W.s_first_out) {
             // decimate[0] is wanted (the GUI's spectrum tap, parity tests)

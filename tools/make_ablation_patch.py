@@ -3,7 +3,8 @@
 
 The phase ablations of mix_item (-DSDRX_ABL_LOAD / CP / NCO / MIX / CARRY / ST0 / ST1 / LDS / STORE / CONFLICT: each removes one
 phase; WRONG results by design -- the phase-cost study of profiles/README.md) are not part of the product source: they live in
-the patch this script writes, which tools/ab_build.sh applies to a scratch copy.  Run it again after editing mix_item; it
+the patch this script writes, which tools/ab_build.sh applies to a scratch copy.  Run it again after editing mix_item or its helpers (load_run_tile and nco_mix are late_item's too: LOAD / NCO / MIX remove
+those phases from both); it
 fails loudly when an anchor no longer matches.  (The LDS-DMA prefetch of rounds 3-4, -DSDRX_GLDS, was measured slower twice
 and is only in the history: `git show 6224116:sdrreceiver_amd/csrc/kernels.hip`.)"""
 import difflib
@@ -22,13 +23,13 @@ EDITS = [
     const int first_out = D.n_in == 12345 ? W.s_first_out : 0x7fffffff; // ablation: nothing is ever emitted
 #endif
     const int lane16 = (W.s_begin >> 4) + lane;""", 1),
-    ("""                const v4f v = gldv4(src + 64 * i); // tile_unit(c, i, l) = tile_unit(c, 0, l) + 64 i
+    ("""        const v4f v = gldv4(src + 64 * i); // tile_unit(c, i, l) = tile_unit(c, 0, l) + 64 i
 """,
      """#ifndef SDRX_ABL_LOAD
-                const v4f v = gldv4(src + 64 * i); // tile_unit(c, i, l) = tile_unit(c, 0, l) + 64 i
+        const v4f v = gldv4(src + 64 * i); // tile_unit(c, i, l) = tile_unit(c, 0, l) + 64 i
 #else
-                v4f v = {1.f * lane, 2.f, 3.f * base, 4.f * i}; // ablation: no global loads
-                asm volatile("" : "+v"(v));
+        v4f v = {1.f, 2.f, 3.f, 4.f * i}; // ablation: no global loads
+        asm volatile("" : "+v"(v));
 #endif
 """, 1),
     ("""            o_next = gldv2(cp_of(base + kChunk < W.s_end ? base + kChunk : base)); // (always issued -- and therefore counted, like the stores)
@@ -40,58 +41,56 @@ EDITS = [
             asm volatile("" : "+v"(o_next));
 #endif
 """, 1),
-    ("""                o = nco_step_pk(o, rot);
-                v2f m = o;
-                if (i == 0 && first_ever)
-                    m = gldv2(D.cp + (D.L >> 4));
-                x[i] = cmul(m, x[i]);
-            }
-        } else {
-            nco_mix_fast16(o, Dp->rk, x);
+    ("""            o = nco_step_pk(o, rot);
+            v2f m = o;
+            if (i == 0 && first_ever)
+                m = gldv2(last);
+            x[i] = cmul(m, x[i]);
         }
-
-        if (dd == 0) {""",
+    } else {
+        nco_mix_fast16(o, rk, x);
+    }
+}""",
      """#ifndef SDRX_ABL_NCO
-                o = nco_step_pk(o, rot);
+            o = nco_step_pk(o, rot);
 #else
-                asm volatile("" : "+v"(o)); // ablation: keep the value opaque, skip the recurrence
+            asm volatile("" : "+v"(o)); // ablation: keep the value opaque, skip the recurrence
 #endif
-                v2f m = o;
-                if (i == 0 && first_ever)
-                    m = gldv2(D.cp + (D.L >> 4));
+            v2f m = o;
+            if (i == 0 && first_ever)
+                m = gldv2(last);
 #ifndef SDRX_ABL_MIX
-                x[i] = cmul(m, x[i]);
+            x[i] = cmul(m, x[i]);
 #else
-                x[i] = x[i] + m;
+            x[i] = x[i] + m;
 #endif
-            }
-        } else {
+        }
+    } else {
 #if !defined(SDRX_ABL_NCO) && !defined(SDRX_ABL_MIX)
-            nco_mix_fast16(o, Dp->rk, x);
+        nco_mix_fast16(o, rk, x);
 #else
 #pragma unroll
-            for (int i = 0; i < kRun; ++i)
-                x[i] = x[i] + o; // ablation: neither the rotations nor the mixer
+        for (int i = 0; i < kRun; ++i)
+            x[i] = x[i] + o; // ablation: neither the rotations nor the mixer
 #endif
-        }
-
-        if (dd == 0) {""", 1),
-    ("""        wave_sync(); // car0/car1 of the previous chunk (or the initial state) are visible
-        {
-            const v4f *c4 = reinterpret_cast<const v4f *>(car0); // broadcast reads""",
-     """#ifdef SDRX_ABL_CARRY
-        for (int q = 0; q < 10; ++q) ext0[q] = x[q]; // ablation: no LDS carry, no DPP
+    }
+}""", 1),
+    ("""        halo_stage0(car0, ext0, lane);
+""",
+     """#ifndef SDRX_ABL_CARRY
+        halo_stage0(car0, ext0, lane);
 #else
-        wave_sync(); // car0/car1 of the previous chunk (or the initial state) are visible
-        {
-            const v4f *c4 = reinterpret_cast<const v4f *>(car0); // broadcast reads""", 1),
-    ("""            c4[3] = cat2(x[14], x[15]);
-        }
-        v2f ext1[10 + 8];""",
-     """            c4[3] = cat2(x[14], x[15]);
-        }
+        for (int q = 0; q < 10; ++q) ext0[q] = x[q]; // ablation: no LDS carry, no DPP
 #endif
-        v2f ext1[10 + 8];""", 1),
+""", 1),
+    ("""        halo_stage1(car1, ext1, lane);
+""",
+     """#ifndef SDRX_ABL_CARRY
+        halo_stage1(car1, ext1, lane);
+#else
+        for (int q = 0; q < 10; ++q) ext1[q] = y[q & 7];
+#endif
+""", 1),
     ("""        hb_regs<EXACT, 8>(ext0, y);
 """,
      """#ifndef SDRX_ABL_ST0
@@ -100,22 +99,6 @@ EDITS = [
 #pragma unroll
         for (int j = 0; j < 8; ++j) // ablation: 1 add instead of the dot product
             y[j] = ext0[2 * j] + ext0[2 * j + 10];
-#endif
-""", 1),
-    ("""        // 4. stage 1 in registers.  Halo y[-8,-6,-5,-4,-3,-2,-1] = previous lane's y[0,2..7],
-        //    y[-10] = the lane before that one's y[6] (a second shift of the shifted y[6]).
-        {""",
-     """#ifdef SDRX_ABL_CARRY
-        for (int q = 0; q < 10; ++q) ext1[q] = y[q & 7];
-#else
-        // 4. stage 1 in registers.  Halo y[-8,-6,-5,-4,-3,-2,-1] = previous lane's y[0,2..7],
-        //    y[-10] = the lane before that one's y[6] (a second shift of the shifted y[6]).
-        {""", 1),
-    ("""        if (lane == 62)
-            car1[0] = y[6];
-""",
-     """        if (lane == 62)
-            car1[0] = y[6];
 #endif
 """, 1),
     ("""        hb_regs<EXACT, 4>(ext1, z);
