@@ -632,9 +632,9 @@ def main():
         # dongle bytes WITH the DC-bias removal of the shipped sdr_25E profile (correct_dc_bias=1, sdrj.cpp:271-286), bit for bit
         # the reference's sequentially rounded recurrence.  Input: the capture-like stream (sdrreceiver_amd/synth.py: noise,
         # carriers, bursts and the ADC OFFSET the correction exists for), 8 frames in turn after 8 frames of settling -- the
-        # recurrence runs in verified 1024-sample blocks where it can (k_dc_chain_spec) and sample by sample where it cannot,
-        # and with NO offset at all (the zero-mean LCG frames of the other legs: the estimate wanders through zero, binade after
-        # binade) it mostly cannot: that worst case is `u8_dc_zero_offset_sync_ms` (~ the every-sample evaluation's 2.4 ms).
+        # recurrence runs in verified steps of 8 x 1024 samples where it can (k_dc_chain_spec) and sample by sample where it
+        # cannot.  `u8_dc_zero_offset_sync_ms`: the zero-mean LCG frames of the other legs, NO offset at all (the estimate wanders
+        # through zero, binade after binade).
         cap = synth.capture_like_u8(8, topo.frame, topo.fs) if topo.fs == 1536000 else None
         cap = [cap[2 * topo.frame * f: 2 * topo.frame * (f + 1)] for f in range(8)] if cap is not None else [(job.frames_np[0] + 128).astype(np.uint8)]
         for b_ in cap:
@@ -656,6 +656,7 @@ def main():
         abi["u8_dc_ms_per_frame"] = abi["u8_dc_pipelined_ms"]
         st1 = rx.stats()
         abi["u8_dc_blocks"] = {"walked": int(st1["dc_blocks"] - st0["dc_blocks"]), "redone_sequentially": int(st1["dc_fallback_blocks"] - st0["dc_fallback_blocks"]),
+                               "taken_again_on_their_own": int(st1["dc_retried_blocks"] - st0["dc_retried_blocks"]),
                                "input": "capture-like stream (offsets +1.3 / -0.7 LSB), frames 8-23 of the run"}
         u8z = (job.frames_np[0] + 127).astype(np.uint8)
         rx.process_u8(u8z, correct_dc=True)

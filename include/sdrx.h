@@ -122,10 +122,13 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
  *                 correlated from step to step), so 1 is NOT within the 1e-5 parity tolerance
  *                 of the reference unless the offset is well below 1 LSB.
  *   "dc_speculative" 1 (default) | 0: how the bit-exact recurrence is evaluated.  1 = blocks of 1024 samples as integer
- *                 prefix sums of the mantissa, each block VERIFIED (binade, sign and the rounding of avept * (1 - 1e-6)
- *                 unchanged through the block, no exact ties) and redone with the sequential operations where the
- *                 verification fails: bit-exact by construction, ~0.1 ms per 384 000-sample frame with an offset in steady
- *                 state, at worst the sequential time (sdrx_stats.dc_blocks / dc_fallback_blocks).  0 = the sequential
+ *                 prefix sums of the mantissa, several blocks side by side per step, each step VERIFIED (binade, sign
+ *                 and the rounding of avept * (1 - 1e-6) unchanged through it, no exact ties), taken again block by
+ *                 block where that fails and redone with the sequential operations where a single block fails: bit-exact
+ *                 by construction, at worst the sequential time (sdrx_stats.dc_blocks / dc_retried_blocks /
+ *                 dc_fallback_blocks).
+ *   "dc_blocks_per_step" 1 | 2 | 4 | 8: how many 1024-sample blocks one step of that evaluation takes side by
+ *                 side (= waves of the one workgroup per component).  Same results for every value.  0 = the sequential
  *                 recurrence for every sample (~2.0 ms per frame: two waves, each alone with its dependent chain): A/B switch. */
 int sdrx_set_option(sdrx_ctx *ctx, const char *name, int value);
 /* All of vfo::init for every node: NCO tables (oscillator.cpp:4-32), low-pass designs
@@ -301,6 +304,8 @@ typedef struct sdrx_stats {
                                          /*   per frame, warm-up chunks of segments included  */
     int64_t dc_blocks;                   /* exact DC-bias removal (sdrx_process_u8 .. correct_dc): 1024-sample blocks of one */
     int64_t dc_fallback_blocks;          /*   component walked so far / of those, redone with the sequential operations     */
+    int64_t dc_retried_blocks;           /*   / taken again on their own because the step of several blocks they were part of */
+                                         /*   did not verify as a whole (and then did: not counted as redone)                */
 } sdrx_stats;
 int sdrx_get_stats(sdrx_ctx *ctx, sdrx_stats *out);
 /* Per-kernel GPU time from HIP events recorded on the launch stream.  enable=1 brackets every

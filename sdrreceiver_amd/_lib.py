@@ -39,7 +39,7 @@ class StatsC(C.Structure):
         ("n_vfos", C.c_int32), ("n_leaves", C.c_int32), ("n_levels", C.c_int32), ("exact", C.c_int32),
         ("algorithmic_bytes_per_frame", C.c_int64), ("vfo_samples_per_frame", C.c_int64),
         ("device_bytes", C.c_int64), ("frames", C.c_int64), ("mix_chunks_per_frame", C.c_int64),
-        ("dc_blocks", C.c_int64), ("dc_fallback_blocks", C.c_int64),
+        ("dc_blocks", C.c_int64), ("dc_fallback_blocks", C.c_int64), ("dc_retried_blocks", C.c_int64),
     ]
 
 

@@ -514,20 +514,20 @@ __global__ __launch_bounds__(64) void k_dc_chain(const float *__restrict__ P, fl
 // m_u's would, and ties are excluded anyway) --, the tie test out of the exact residual p - (v - C).
 // (The reference's estimate LIVES at such a threshold: below T the decrement r_lo is smaller than the mean of q, above it
 // r_lo + 1 is larger, so m climbs to T and then hovers around it -- 1.2353 for an offset of 1.3 LSB, not 1.3.)
-// One wave per component walks the frame block by block; lane l owns samples 16 l .. 16 l + 15 of the block.  Every lane runs
-// the integer recurrence for its 16 samples from a SPECULATED start value; the lanes' totals are scanned (6 DPP steps) into
-// new start values; repeated until no start value changes -- then every lane started from the true value (lane 0 always does;
-// lane l does if all before it did) and its 16 steps are the recurrence itself.  The first guess -- r constant over the block
-// -- is already the answer unless some lane's run comes across T.  A converged block is then VERIFIED: every m it visited,
-// INCLUDING the last, inside [start of r_lo's run, end of (r_lo + 1)'s run) and >= 2^23 + 32 (nothing may touch the binade's
-// lower end, where fl(a keep) falls into the finer grid below), no exact tie.  A block that does not converge in kDcMaxIter
-// rounds or fails the verification -- the binade or the sign changes inside it, a tie, |a| < 2^-9 (start-up: p is no longer
-// small against a), an estimate PINNED to T by steps of an ulp or two (an offset many times the noise) -- is redone with the
-// rounded float operations themselves, one dependent mul + add pair per sample: k_dc_chain's arithmetic, 1024 steps.
-// Verified blocks are bit-exact BY CONSTRUCTION, the others by definition (sdrx_stats.dc_blocks / dc_fallback_blocks say how
-// many there were of each).  Output as k_dc_chain's: A[c][j] = avept before sample 16 j, for k_dc_apply.
+// One workgroup per component walks the frame, NW blocks per step, one wave each; lane l owns samples 16 l .. 16 l + 15 of its
+// wave's block.  Every lane runs the integer recurrence for its 16 samples from a SPECULATED start value; a step stands once
+// every lane -- of every wave -- started where its predecessor ended (dc_spec_blocks below: how the start values are found).
+// Lane 0 of wave 0 always starts from the true value, lane l does if all before it did: then the 16 steps of every lane are the
+// recurrence itself.  Such a step is then VERIFIED: every m it visited, INCLUDING the last, inside [start of r_lo's run, end of
+// (r_lo + 1)'s run) and >= 2^23 + 32 (nothing may touch the binade's lower end, where fl(a keep) falls into the finer grid
+// below), no exact tie.  A step that does not stand within kDcMaxIter rounds or fails the verification -- the binade or the
+// sign changes inside it, a tie, |a| < 2^-9 (start-up: p is no longer small against a) -- is taken again block by block, each
+// with its own context, and a block that fails on its own is redone with the rounded float operations themselves, one dependent
+// mul + add pair per sample: k_dc_chain's arithmetic, 1024 steps.
+// Verified blocks are bit-exact BY CONSTRUCTION, the others by definition (sdrx_stats.dc_blocks / dc_retried_blocks /
+// dc_fallback_blocks say how many there were of each).  Output as k_dc_chain's: A[c][j] = avept before sample 16 j, for k_dc_apply.
 constexpr int kDcBlock = 64 * kRun; // samples per block: a lane's run is one stored estimate's 16 samples
-constexpr int kDcMaxIter = 6;       // rounds of "every lane from its speculated start value" before a block is given up
+constexpr int kDcMaxIter = 24;      // rounds of "every lane from its speculated start value" before a step is given up (a quiet front end takes up to ~16)
 __device__ __forceinline__ int wave_inclusive_scan(int x)
 {
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); // row_shr:1
@@ -538,117 +538,299 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
     return x;
 }
-__global__ __launch_bounds__(64) void k_dc_chain_spec(const float *__restrict__ P, float *__restrict__ A, int n_complex, int stride,
-                                                      float *__restrict__ state, unsigned long long *__restrict__ counters)
+// NW waves, NW consecutive blocks side by side: what one wave does for its block, one 16-byte record per wave and round exchanged
+// through LDS (two sets alternating: one barrier per round).  Every wave derives the SAME context (binade, sign, T, r_lo) from the
+// accumulator before the first of the NW blocks.
+// Finding the start values.  A lane's total is a function of its start value: tot(x + d) - tot(x) is between -d and 0 (every step
+// merges the states -1 and 0: two trajectories only ever come closer).  Each round EVALUATES every lane's run at its current start
+// value (the integer recurrence itself) and looks at the gaps  g_l = start_l + tot_l - start_(l+1)  between a run's end and the
+// start the next lane assumed: all gaps zero = every lane started where its predecessor ended = the recurrence itself.
+// Otherwise the starts move by the solution u of  u_(l+1) = (1 + s_l) u_l + g_l,  u_0 = 0  (a scan of affine maps: DPP inside a
+// wave, the waves' composed maps through LDS), s_l = the lane's secant slope out of its last two evaluations (0 at first: then the
+// step is "every start := the sum of the totals before it").  With all slopes 0 that iteration needs as many rounds as there
+// are lanes whose runs come across T one after the other; an estimate hovering at T with small steps (a quiet front end) or
+// pinned to it (an offset many times the noise) has slopes near -1 -- every run forgets where it started -- and the plain sums
+// overshoot for dozens of rounds, where the affine step lands next to the answer at once.  Near T the first round evaluates a
+// second start value too ("the estimate stays where it is") to have slopes from the beginning.
+// Nothing here has to be exact except the evaluation: a block is only accepted in a round that found every gap zero, and then
+// VERIFIED (that round's runs all stayed inside the context, no tie).  NW = 1: no LDS, no barrier.
+// In: `acc` (uniform over the workgroup), the lane's 16 products `p`, nv = lanes of this wave that hold samples, last_wave = the
+// last wave that holds any.  Out: `start` = avept before the lane's first sample, `acc_out` = avept after the last block;
+// false = nothing to be used.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float old, float src)
 {
-    const int c = blockIdx.x, lane = threadIdx.x; // component; lane
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xf, false));
+}
+// Inclusive scan over the wave's lanes of the maps x -> A x + B (lane l: its own map after those of the lanes before it).  One
+// step = two instructions with the DPP operand in place: B += A * B[l - n] (lanes without a source read 0), A *= A[l - n] (lanes
+// without a source are disabled: A stays) -- and the two wait states a DPP read of a just-written VGPR needs.
+#define SDRX_AFFINE_STEP(ctrl, fill) "v_fmac_f32_dpp %1, %1, %0 " ctrl " bank_mask:0xf bound_ctrl:1\n\tv_mul_f32_dpp %0, %0, %0 " ctrl " bank_mask:0xf\n\t" fill
+__device__ __forceinline__ void affine_scan_wave(float &A, float &B)
+{
+    asm volatile("s_nop 1\n\t"
+                 SDRX_AFFINE_STEP("row_shr:1 row_mask:0xf", "s_nop 0\n\t")
+                 SDRX_AFFINE_STEP("row_shr:2 row_mask:0xf", "s_nop 0\n\t")
+                 SDRX_AFFINE_STEP("row_shr:4 row_mask:0xf", "s_nop 0\n\t")
+                 SDRX_AFFINE_STEP("row_shr:8 row_mask:0xf", "s_nop 0\n\t")
+                 SDRX_AFFINE_STEP("row_bcast:15 row_mask:0xa", "s_nop 0\n\t")
+                 SDRX_AFFINE_STEP("row_bcast:31 row_mask:0xc", "s_nop 1")
+                 : "+v"(A), "+v"(B));
+}
+__device__ __forceinline__ void affine_scan_lanes8(float &A, float &B, int n) // the same over the first n <= 8 lanes
+{
+    if (n > 4)
+        asm volatile("s_nop 1\n\t" SDRX_AFFINE_STEP("row_shr:1 row_mask:0xf", "s_nop 0\n\t") SDRX_AFFINE_STEP("row_shr:2 row_mask:0xf", "s_nop 0\n\t")
+                         SDRX_AFFINE_STEP("row_shr:4 row_mask:0xf", "s_nop 1")
+                     : "+v"(A), "+v"(B));
+    else if (n > 2)
+        asm volatile("s_nop 1\n\t" SDRX_AFFINE_STEP("row_shr:1 row_mask:0xf", "s_nop 0\n\t") SDRX_AFFINE_STEP("row_shr:2 row_mask:0xf", "s_nop 1") : "+v"(A), "+v"(B));
+    else
+        asm volatile("s_nop 1\n\t" SDRX_AFFINE_STEP("row_shr:1 row_mask:0xf", "s_nop 1") : "+v"(A), "+v"(B));
+}
+template <int NW, typename AfterInputs>
+__device__ __forceinline__ bool dc_spec_blocks(float acc, const float *p, int nv, int lane, int wave, int last_wave, int4 *xch, int &par, int rounds,
+                                               float &start, float &acc_out, AfterInputs &&after_inputs)
+{
+    const unsigned bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc));
+    const unsigned ex = (bits >> 23) & 255u, sign = bits & 0x80000000u;
+    const int m0 = (int)((bits & 0x7fffffu) | 0x800000u);
+    // r(m) = r for  r 2^24 <= 17 m + 2^23 < (r + 1) 2^24, i.e. from run_start(r) up to run_start(r + 1)
+    auto run_start = [](int r) { return (int)((((unsigned)r << 24) - (1u << 23) + 16u) / 17u); };
+    const int r0 = (int)((17u * (unsigned)m0 + (1u << 23)) >> 24);
+    const int lo0 = run_start(r0), hi0 = run_start(r0 + 1);
+    const bool near_lo = m0 - lo0 < hi0 - m0;
+    const int T = near_lo ? lo0 : hi0, rlo = near_lo ? r0 - 1 : r0;
+    const int lo = max(run_start(rlo), (1 << 23) + 32), hi = min(run_start(rlo + 2), 1 << 24);
+    const bool ctx_ok = ex >= 118u && ex < 255u && m0 >= lo && m0 < hi; // |a| >= 2^-9: |p| / ulp < 2^21
+    if (!ctx_ok) // (the same decision in every wave: they hold the same accumulator)
+        return false;
+    const unsigned cb = sign | (ex << 23) | 0x400000u;
+    const float C = __builtin_bit_cast(float, cb);                                   // s 1.5 2^23 ulp
+    const float half_ulp = __builtin_bit_cast(float, (ex >= 25u ? ex - 24u : 1u) << 23);
+    // bits(v) - bits(C) = the change of the MAGNITUDE's mantissa (for a negative accumulator -RN(p / ulp), as it must be);
+    // e[i] = that - r_lo - 1, so that a step is  z' = z + e[i] + [z < 0]  for z = m - T
+    const int ebase = (int)cb + rlo + 1;
+    float worst = 0.f; // max |residual|: never above half an ulp, equal to it = an exact tie
+    int e[kRun], tot = 0;
+#pragma unroll
+    for (int i = 0; i < kRun; i += 2) {
+        const v2f pp = {p[i], p[i + 1]}, CC = {C, C};
+        const v2f v = CC + pp;           // (v_pk_add_f32: two samples per instruction)
+        const v2f resid = pp - (v - CC); // exact
+        const float v0 = v.x, v1 = v.y;  // (not __builtin_bit_cast(int, v.y): this compiler takes element 0 for it)
+        worst = fmaxf(worst, fmaxf(fabsf(resid.x), fabsf(resid.y)));
+        e[i] = __builtin_bit_cast(int, v0) - ebase;
+        e[i + 1] = __builtin_bit_cast(int, v1) - ebase;
+        tot += e[i] + e[i + 1];
+    }
+    asm volatile("" : "+v"(tot) : : "memory"); // (the products have arrived and are consumed)
+    after_inputs();
+    const bool tie = worst == half_ulp;
+    const bool mine = lane < nv;
+    const int S = m0 - T;
+    // a lane behind this one takes over where this one ends (in this wave, or lane 0 of the next)
+    const bool linked = lane + 1 < nv || (NW > 1 && lane == 63 && wave < last_wave);
+    // the waves' records of a round -> what the waves before this one make of u = 0, the same for the next wave, the flags of all
+    // (1: a gap somewhere, 2: a run left the context) and the last block's end
+    auto exchange = [&](float A, float B, int flags, int end, float &u_in, float &u_next, int &end_last) {
+        if constexpr (NW == 1) {
+            u_in = 0.f, u_next = B, end_last = end;
+            return flags;
+        } else {
+            if (lane == 0)
+                xch[par * NW + wave] = make_int4(__builtin_bit_cast(int, A), __builtin_bit_cast(int, B), flags, end);
+            __syncthreads();
+            // lane w < NW takes wave w's record; the maps composed over those lanes (three DPP steps), the flags by ballot
+            const int4 r = xch[par * NW + (lane < NW ? lane : NW - 1)];
+            const bool rec = lane < NW;
+            float Ar = rec ? __builtin_bit_cast(float, r.x) : 1.0f, Br = rec ? __builtin_bit_cast(float, r.y) : 0.0f;
+            affine_scan_lanes8(Ar, Br, NW);
+            const int Bi = __builtin_bit_cast(int, Br);
+            u_in = wave > 0 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(Bi, wave > 0 ? wave - 1 : 0)) : 0.f;
+            u_next = __builtin_bit_cast(float, __builtin_amdgcn_readlane(Bi, wave));
+            end_last = __builtin_amdgcn_readlane(r.w, last_wave);
+            par ^= 1;
+            return (__builtin_amdgcn_ballot_w64(rec && (r.z & 1)) != 0ull ? 1 : 0) | (__builtin_amdgcn_ballot_w64(rec && (r.z & 2)) != 0ull ? 2 : 0);
+        }
+    };
+    // first guess.  With t steps before it a lane's start value lies between  a = S + (the sum of their e)  -- no step saw the
+    // estimate below T -- and  b = a + t  -- every step did --: take the one of a, 0, b in the middle ("at T, unless not even the
+    // extreme count gets it there").  An estimate that stays on its side of T through the block makes that exact; one that hovers
+    // at T is guessed to within its excursion.  In integers (these sums go up to 2^31; the gaps of the rounds are counts of steps).
+    int zs, next0; // this lane's start value minus T; the same of the lane behind lane 63
+    {
+        tot = mine ? tot : 0;
+        const int incl = wave_inclusive_scan(tot);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        int before = 0;
+        if constexpr (NW > 1) {
+            if (lane == 0)
+                xch[par * NW + wave] = make_int4(total, 0, 0, 0);
+            __syncthreads();
+            int t = lane < NW ? xch[par * NW + (lane < NW ? lane : NW - 1)].x : 0; // lane w: wave w's total
+            t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xf, 0xf, true);        // row_shr:1, 2, 4: the sums up to wave w
+            if constexpr (NW > 2)
+                t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xf, 0xf, true);
+            if constexpr (NW > 4)
+                t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xf, true);
+            before = wave > 0 ? __builtin_amdgcn_readlane(t, wave > 0 ? wave - 1 : 0) : 0;
+            par ^= 1;
+        }
+        const int a = S + before + (incl - tot), a_next = S + before + total;
+        zs = a >= 0 ? a : min(0, a + kRun * (64 * wave + lane));
+        next0 = a_next >= 0 ? a_next : min(0, a_next + kRun * 64 * (wave + 1));
+    }
+    float slope = 0.f;
+    int zs_prev = 0, tot_prev = 0;
+    for (int it = 0; it < rounds; ++it) {
+        int z = zs, zmin = zs, zmax = zs;
+#pragma unroll
+        for (int i = 0; i < kRun; ++i) {
+            z = z + e[i] + (int)((unsigned)z >> 31);
+            zmin = min(zmin, z);
+            zmax = max(zmax, z);
+        }
+        tot = mine ? z - zs : 0;
+        const int end = zs + tot;
+        const int zs_behind = __builtin_amdgcn_update_dpp(next0, zs, 0x130, 0xf, 0xf, false); // wave_shl:1 (lane 63: next0)
+        const int gap = linked ? end - zs_behind : 0;
+        const bool ok = !mine || (!tie && zmin + T >= lo && zmax + T < hi);
+        const int flags = (__builtin_amdgcn_ballot_w64(gap != 0) != 0ull ? 1 : 0) | (__builtin_amdgcn_ballot_w64(!ok) != 0ull ? 2 : 0);
+        // the slope of this lane's total in its start value: the secant of its last two evaluations; before there are two, out
+        // of the run itself -- one that saw both sides of T has its 16 merge points spread over about the range it covered
+        if (it == 0)
+            slope = zmin < 0 && zmax >= 0 ? -fminf(1.f, (float)kRun * __builtin_amdgcn_rcpf((float)(zmax - zmin + 1))) : 0.f;
+        else if (zs != zs_prev)
+            slope = fminf(0.f, fmaxf(-1.f, (float)(tot - tot_prev) * __builtin_amdgcn_rcpf((float)(zs - zs_prev))));
+        zs_prev = zs, tot_prev = tot;
+        float A = linked ? 1.0f + slope : 1.0f, B = (float)gap;
+        affine_scan_wave(A, B);
+        const float Aw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, A), 63));
+        const float Bw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, B), 63));
+        const int end_mine = __builtin_amdgcn_readlane(end, nv > 0 ? nv - 1 : 0);
+        float u_in = 0.f, u_next = 0.f;
+        int end_last = end_mine;
+        const int f = exchange(Aw, Bw, flags, end_mine, u_in, u_next, end_last);
+        if (!(f & 1)) { // every lane of every wave started this round where its predecessor ended
+            if (f & 2)
+                return false;
+            const unsigned hi_bits = sign | ((ex - 1u) << 23); // + a mantissa with its leading one = the float
+            start = __builtin_bit_cast(float, hi_bits + (unsigned)(zs + T));
+            acc_out = __builtin_bit_cast(float, hi_bits + (unsigned)(end_last + T));
+            return true;
+        }
+        const float Ae = dpp_f32<0x138, 0xf>(1.0f, A), Be = dpp_f32<0x138, 0xf>(0.0f, B); // wave_shr:1: the maps of the lanes BEFORE this one
+        zs += (int)__builtin_rintf(__builtin_fmaf(Ae, u_in, Be));
+        next0 += (int)__builtin_rintf(u_next);
+    }
+    return false;
+}
+// The rounded operations themselves on one wave's block, lane after lane: every lane runs the 16 steps on its own products from
+// the uniform accumulator, lane l's result is the accumulator of the next round.  Returns the accumulator after the block.
+__device__ __forceinline__ float dc_sequential_block(float acc, const float *p, int nv, int lane, float &start)
+{
+    const float keep = 1.0f - 0.000001f;
+    start = acc;
+    for (int l = 0; l < nv; ++l) {
+        float t = acc;
+        if (lane == l)
+            start = acc;
+#pragma unroll
+        for (int i = 0; i < kRun; ++i)
+            t = t * keep + p[i]; // -ffp-contract=off: v_mul_f32, v_add_f32
+        acc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), l));
+    }
+    return acc;
+}
+// One workgroup of NW waves per component walks the frame NW blocks at a time.  A step that does not verify as a whole is
+// taken again wave after wave -- each block on its own, from the accumulator its predecessor leaves in LDS: with its own
+// context, and with the rounded operations if that does not verify either -- so that one bad spot costs its own 1024 samples
+// the sequential time and its NW - 1 neighbours the one-wave time.
+// counters: [0] blocks walked, [1] blocks redone with the sequential operations, [2] blocks taken again on their own
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_dc_chain_spec(const float *__restrict__ P, float *__restrict__ A, int n_complex, int stride,
+                                                           float *__restrict__ state, unsigned long long *__restrict__ counters, int rounds)
+{
+    __shared__ int4 xch[2 * NW];
+    __shared__ float handover[2];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // component; lane; wave
     const float *p_c = P + (size_t)c * stride;
     float *a_c = A + (size_t)c * (stride >> 4);
-    const float keep = 1.0f - 0.000001f;
-    float acc = state[c]; // (wave-uniform throughout)
+    float acc = state[c]; // (uniform over the workgroup throughout)
     const int nblk = (n_complex + kDcBlock - 1) / kDcBlock;
-    unsigned fallbacks = 0;
+    unsigned fallbacks = 0, retried = 0;
+    int par = 0;
     float p[kRun], pn[kRun];
-    auto load = [&](int b, float *dst) { // lane's 16 products of block b (the padding behind the frame is zero and never used)
-        const float4 *src = reinterpret_cast<const float4 *>(p_c + (size_t)b * kDcBlock + lane * kRun);
+    auto load = [&](int b, float *dst) { // lane's 16 products of block b; behind the frame the last block's again (never used) --
+        // ALWAYS four loads: behind a branch the compiler could not count them and would wait for the prefetch where it only
+        // needs the block before it
+        const float4 *src = reinterpret_cast<const float4 *>(p_c + (size_t)min(b, nblk - 1) * kDcBlock + lane * kRun);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const v4f v = gldv4(src + i);
             dst[4 * i] = v.x, dst[4 * i + 1] = v.y, dst[4 * i + 2] = v.z, dst[4 * i + 3] = v.w;
         }
     };
-    // one block: `p` holds the lane's products of block b, `pn` receives those of block b + 1 meanwhile
-    auto block = [&](int b, float *p, float *pn) {
-        if (b + 1 < nblk)
-            load(b + 1, pn);
-        const int nv = min(64, (n_complex - b * kDcBlock) >> 4); // lanes that hold samples (frames are multiples of 16)
-        const unsigned bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc));
-        const unsigned ex = (bits >> 23) & 255u, sign = bits & 0x80000000u;
-        const int m0 = (int)((bits & 0x7fffffu) | 0x800000u);
-        // r(m) = r for  r 2^24 <= 17 m + 2^23 < (r + 1) 2^24, i.e. from run_start(r) up to run_start(r + 1)
-        auto run_start = [](int r) { return (int)((((unsigned)r << 24) - (1u << 23) + 16u) / 17u); };
-        const int r0 = (int)((17u * (unsigned)m0 + (1u << 23)) >> 24);
-        const int lo0 = run_start(r0), hi0 = run_start(r0 + 1);
-        const bool near_lo = m0 - lo0 < hi0 - m0;
-        const int T = near_lo ? lo0 : hi0, rlo = near_lo ? r0 - 1 : r0;
-        const int lo = max(run_start(rlo), (1 << 23) + 32), hi = min(run_start(rlo + 2), 1 << 24);
-        const bool ctx_ok = ex >= 118u && ex < 255u && m0 >= lo && m0 < hi; // |a| >= 2^-9: |p| / ulp < 2^21
-        const unsigned cb = sign | (ex << 23) | 0x400000u;
-        const float C = __builtin_bit_cast(float, cb);                                   // s 1.5 2^23 ulp
-        const float half_ulp = __builtin_bit_cast(float, (ex >= 25u ? ex - 24u : 1u) << 23);
-        // bits(v) - bits(C) = the change of the MAGNITUDE's mantissa (for a negative accumulator -RN(p / ulp), as it must be);
-        // e[i] = that - r_lo - 1, so that a step is  z' = z + e[i] + [z < 0]  for z = m - T
-        const int ebase = (int)cb + rlo + 1;
-        bool tie = false;
-        int e[kRun], tot0 = 0;
-#pragma unroll
-        for (int i = 0; i < kRun; ++i) {
-            const float v = C + p[i];
-            const float resid = p[i] - (v - C); // exact
-            tie |= fabsf(resid) == half_ulp;
-            e[i] = __builtin_bit_cast(int, v) - ebase;
-            tot0 += e[i];
-        }
-        const bool mine = lane < nv;
-        tot0 = mine ? tot0 + kRun * (rlo + 1 - r0) : 0; // the lane's 16 steps with r = r0 throughout: the first guess
-        int zs = m0 - T + (wave_inclusive_scan(tot0) - tot0), zend = zs, zmin = zs, zmax = zs; // start value of this lane's run, minus T
-        bool converged = false;
-        for (int it = 0; it < kDcMaxIter && ctx_ok; ++it) {
-            int z = zs;
-            zmin = zmax = zs;
-#pragma unroll
-            for (int i = 0; i < kRun; ++i) {
-                z = z + e[i] + (int)((unsigned)z >> 31);
-                zmin = min(zmin, z);
-                zmax = max(zmax, z);
-            }
-            zend = mine ? z : zs;
-            const int tot = zend - zs;
-            const int znew = m0 - T + (wave_inclusive_scan(tot) - tot);
-            const bool same = znew == zs;
-            zs = znew;
-            if (__builtin_amdgcn_ballot_w64(!same) == 0ull) {
-                converged = true;
-                break;
-            }
-        }
-        const bool ok = !mine || (!tie && zmin + T >= lo && zmax + T < hi);
-        const bool all_ok = converged && __builtin_amdgcn_ballot_w64(!ok) == 0ull;
-        float start; // avept before this lane's first sample
-        if (all_ok) {
-            const unsigned hi_bits = sign | ((ex - 1u) << 23); // + a mantissa with its leading one = the float
-            start = __builtin_bit_cast(float, hi_bits + (unsigned)(zs + T));
-            const unsigned end_m = (unsigned)(__builtin_amdgcn_readlane(zend, 63) + T); // (lanes behind the frame pass their start value on)
-            acc = __builtin_bit_cast(float, hi_bits + end_m);
-        } else {
-            // the rounded operations themselves, lane after lane: every lane runs the 16 steps on its own products from the
-            // uniform accumulator, lane l's result is the accumulator of the next round
-            ++fallbacks;
-            start = acc;
-            for (int l = 0; l < nv; ++l) {
-                float t = acc;
-                if (lane == l)
-                    start = acc;
-#pragma unroll
-                for (int i = 0; i < kRun; ++i)
-                    t = t * keep + p[i]; // -ffp-contract=off: v_mul_f32, v_add_f32
-                acc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), l));
-            }
-        }
-        if (mine)
-            *(SDRX_AS1 float *)(a_c + (size_t)b * 64 + lane) = start;
+    // A step's start values leave in the NEXT step, right behind the point where that one has waited for its products: loads and
+    // stores share one counter here, and a store issued at the end of a step would be waited for along with the products (its
+    // acknowledgement takes longer than the step's arithmetic up to there).
+    float held = 0.f;
+    int held_at = -1;
+    auto store_held = [&]() {
+        if (held_at >= 0)
+            *(SDRX_AS1 float *)(a_c + held_at) = held;
+        held_at = -1;
     };
-    load(0, p);
-    for (int b = 0; b < nblk; b += 2) { // (two blocks per round: the product registers swap roles instead of being copied)
-        block(b, p, pn);
-        if (b + 1 < nblk)
-            block(b + 1, pn, p);
+    // one step: `p` holds the lane's products of block b, `pn` receives those of block b + NW meanwhile
+    auto step = [&](int b, float *p, float *pn) {
+        load(b + NW, pn);
+        const int nv = max(0, min(64, (n_complex - b * kDcBlock) >> 4)); // lanes that hold samples (frames are multiples of 16)
+        const int last_wave = min(NW, nblk - (b - wave)) - 1;            // the last wave that holds any
+        float start = acc, acc_out = acc;
+        if (dc_spec_blocks<NW>(acc, p, nv, lane, wave, last_wave, xch, par, rounds, start, acc_out, store_held)) {
+            acc = acc_out;
+        } else if constexpr (NW == 1) {
+            ++fallbacks;
+            acc = dc_sequential_block(acc, p, nv, lane, start);
+        } else {
+            for (int w = 0; w < NW; ++w) {
+                if (wave == w) {
+                    int none = 0;
+                    if (nv > 0 && dc_spec_blocks<1>(acc, p, nv, lane, 0, 0, nullptr, none, rounds, start, acc_out, [] {})) {
+                        ++retried;
+                        acc = acc_out;
+                    } else if (nv > 0) {
+                        ++fallbacks;
+                        acc = dc_sequential_block(acc, p, nv, lane, start);
+                    }
+                    if (lane == 0)
+                        handover[w & 1] = acc;
+                }
+                __syncthreads();
+                acc = handover[w & 1];
+            }
+        }
+        store_held(); // (only if this step never came to its inputs' end: no context)
+        held = start, held_at = lane < nv ? b * 64 + lane : -1;
+    };
+    load(wave, p);
+    for (int b = wave; b - wave < nblk; b += 2 * NW) { // (two steps per round: the product registers swap roles instead of being copied)
+        step(b, p, pn);
+        if (b - wave + NW < nblk)
+            step(b + NW, pn, p);
     }
+    store_held();
     if (lane == 0) {
-        state[c] = acc;
+        if (wave == 0)
+            state[c] = acc;
         if (counters) {
-            atomicAdd(counters + 0, (unsigned long long)nblk);
-            atomicAdd(counters + 1, (unsigned long long)fallbacks);
+            if (wave == 0)
+                atomicAdd(counters + 0, (unsigned long long)nblk);
+            if (fallbacks)
+                atomicAdd(counters + 1, (unsigned long long)fallbacks);
+            if (retried)
+                atomicAdd(counters + 2, (unsigned long long)retried);
         }
     }
 }

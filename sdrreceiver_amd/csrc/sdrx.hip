@@ -31,7 +31,7 @@
 using namespace sdrx;
 
 static_assert(sizeof(sdrx_vfo_desc) == 56 && offsetof(sdrx_vfo_desc, topic) == 48, "sdrx_vfo_desc ABI layout");
-static_assert(sizeof(sdrx_stats) == 72, "sdrx_stats ABI layout");
+static_assert(sizeof(sdrx_stats) == 80, "sdrx_stats ABI layout");
 
 namespace {
 
@@ -171,7 +171,8 @@ struct sdrx_ctx {
     unsigned char *d_raw_u8[2] = {nullptr, nullptr}; // the same for dongle bytes
     float *d_dc_state = nullptr;   // DC-bias accumulator (exact: [2]; fast: [parity][2])
     float *d_dc_work = nullptr;    // exact DC-bias removal: products P[2][stride] and estimates A[2][stride] of one frame
-    unsigned long long *d_dc_counters = nullptr; // k_dc_chain_spec: [0] blocks walked, [1] blocks redone with the sequential operations
+    unsigned long long *d_dc_counters = nullptr; // k_dc_chain_spec: [0] blocks walked, [1] blocks redone with the sequential operations, [2] blocks taken again on their own
+    int dc_waves = 8;                            // k_dc_chain_spec: blocks per step = waves per workgroup (SDRX_DC_WAVES: 1, 2, 4, 8)
     int dc_work_stride = 0;
     double *d_dc_tab = nullptr;    // fast DC scan: powers of the decay + per-chunk sums behind them
     unsigned long long dc_frames = 0; // frames the fast scan has run on (its state ping-pongs)
@@ -641,6 +642,8 @@ int sdrx_create(sdrx_ctx **out, int device)
     bool ok = hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
     c->upload_kernel = getenv("SDRX_UPLOAD_KERNEL") && atoi(getenv("SDRX_UPLOAD_KERNEL")) != 0;
+    if (getenv("SDRX_DC_WAVES"))
+        c->dc_waves = atoi(getenv("SDRX_DC_WAVES"));
     if (getenv("SDRX_DOWNLOAD_BLOCKS"))
         c->download_blocks = std::max(0, std::min(4096, atoi(getenv("SDRX_DOWNLOAD_BLOCKS"))));
     // odd frames' payloads leave on a copy stream of their own: the next copy's set-up then overlaps the
@@ -708,6 +711,11 @@ int sdrx_set_option(sdrx_ctx *c, const char *name, int value)
         c->opt_dc_blocked = value != 0;
     else if (!strcmp(name, "dc_speculative"))
         c->opt_dc_speculative = value != 0;
+    else if (!strcmp(name, "dc_blocks_per_step")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8)
+            return fail(c, SDRX_EINVAL, "dc_blocks_per_step: 1, 2, 4 or 8");
+        c->dc_waves = value;
+    }
     else if (!strcmp(name, "pipeline"))
         c->opt_pipeline = value != 0;
     else if (!strcmp(name, "fuse"))
@@ -1668,10 +1676,14 @@ int enqueue_u8_device(sdrx_ctx *c, const void *dev_bytes, int n_complex, int cor
                            n_complex, c->dc_work_stride);
         if (c->opt_dc_speculative) {
             if (!c->d_dc_counters) {
-                HIPCHK(c, hipMalloc(&c->d_dc_counters, 2 * sizeof(unsigned long long)));
-                HIPCHK(c, hipMemsetAsync(c->d_dc_counters, 0, 2 * sizeof(unsigned long long), c->stream));
+                HIPCHK(c, hipMalloc(&c->d_dc_counters, 4 * sizeof(unsigned long long)));
+                HIPCHK(c, hipMemsetAsync(c->d_dc_counters, 0, 4 * sizeof(unsigned long long), c->stream));
             }
-            hipLaunchKernelGGL(k_dc_chain_spec, dim3(2), dim3(64), 0, c->stream, Pp, Ap, n_complex, c->dc_work_stride, c->d_dc_state, c->d_dc_counters);
+            // one workgroup per component, dc_waves consecutive 1024-sample blocks per step
+            auto chain = c->dc_waves >= 8 ? k_dc_chain_spec<8> : c->dc_waves >= 4 ? k_dc_chain_spec<4> : c->dc_waves >= 2 ? k_dc_chain_spec<2> : k_dc_chain_spec<1>;
+            const int waves = c->dc_waves >= 8 ? 8 : c->dc_waves >= 4 ? 4 : c->dc_waves >= 2 ? 2 : 1;
+            hipLaunchKernelGGL(chain, dim3(2), dim3(64 * waves), 0, c->stream, Pp, Ap, n_complex, c->dc_work_stride, c->d_dc_state, c->d_dc_counters,
+                               getenv("SDRX_DC_ROUNDS") ? atoi(getenv("SDRX_DC_ROUNDS")) : kDcMaxIter);
         } else {
             hipLaunchKernelGGL(k_dc_chain, dim3(2), dim3(64), 0, c->stream, Pp, Ap, n_complex, c->dc_work_stride, c->d_dc_state);
         }
@@ -2096,12 +2108,13 @@ int sdrx_get_stats(sdrx_ctx *c, sdrx_stats *s)
     s->frames = (int64_t)c->frame_no;
     s->mix_chunks_per_frame = c->mix_chunks;
     if (c->d_dc_counters) { // (waits for what is queued: a measurement call)
-        unsigned long long h[2] = {0, 0};
+        unsigned long long h[3] = {0, 0, 0};
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipMemcpy(h, c->d_dc_counters, sizeof h, hipMemcpyDeviceToHost));
         s->dc_blocks = (int64_t)h[0];
         s->dc_fallback_blocks = (int64_t)h[1];
+        s->dc_retried_blocks = (int64_t)h[2];
     }
     return SDRX_OK;
 }

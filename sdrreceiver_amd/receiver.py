@@ -31,7 +31,8 @@ class Receiver:
 
     def __init__(self, device: int = 0, exact: bool = True, keep_prequant: bool = False, segments: int = 0,
                  dc_blocked_scan: bool = False, pipeline: bool = False, fuse: bool = True, frame_pipeline: bool = True,
-                 fuse_late: bool = True, keep_streams: bool = False, dc_speculative: bool = True):
+                 fuse_late: bool = True, keep_streams: bool = False, dc_speculative: bool = True,
+                 dc_blocks_per_step: int | None = None):
         self.L = _lib.lib()
         h = C.c_void_p()
         rc = self.L.sdrx_create(C.byref(h), int(device))
@@ -52,6 +53,8 @@ class Receiver:
         self._chk(self.L.sdrx_set_option(self.h, b"fuse_late", int(bool(fuse_late))))
         self._chk(self.L.sdrx_set_option(self.h, b"keep_streams", int(bool(keep_streams))))
         self._chk(self.L.sdrx_set_option(self.h, b"dc_speculative", int(bool(dc_speculative))))
+        if dc_blocks_per_step is not None:
+            self._chk(self.L.sdrx_set_option(self.h, b"dc_blocks_per_step", int(dc_blocks_per_step)))
         self.finalized = False
 
     # -- plumbing -----------------------------------------------------------------

@@ -31,7 +31,7 @@ def test_struct_layout_matches_header():
     # sdrx_vfo_desc: i32 i32 f64 i32 i32 i32 f32 i32 i32 i32 i32 char[8]  -> 56 bytes, 8-aligned
     assert C.sizeof(_lib.VfoDescC) == 56 and _lib.VfoDescC.mixer_freq_hz.offset == 8
     assert _lib.VfoDescC.topic.offset == 48
-    assert C.sizeof(_lib.StatsC) == 72
+    assert C.sizeof(_lib.StatsC) == 80
 
 
 def test_no_gpu_means_loud_failure():

@@ -915,7 +915,8 @@ DC_STREAMS = {  # (offset I, offset Q, noise sigma) in LSB
 
 
 @pytest.mark.parametrize("stream", sorted(DC_STREAMS))
-def test_speculative_dc_chain_is_the_sequential_recurrence(Receiver, stream):
+@pytest.mark.parametrize("per_step", [1, 4, 8])
+def test_speculative_dc_chain_is_the_sequential_recurrence(Receiver, stream, per_step):
     """k_dc_chain_spec evaluates avept = fl(fl(avept * (1 - 1e-6)) + fl(1e-6 * curr)) (sdrj.cpp:277-283) a block of 1 024 samples
     at a time as an integer recurrence of the mantissa (every lane its 16 samples from a speculated start value, repeated
     until the start values stand), verifies the block and falls back to the rounded operations where it does not converge
@@ -924,17 +925,18 @@ def test_speculative_dc_chain_is_the_sequential_recurrence(Receiver, stream):
     rounding it then hovers around), offsets next to a binade boundary, both signs, an estimate that crosses zero, estimates
     pinned to their threshold by steps of an ulp: the DC-corrected frame bit for bit the oracle's, and identical to the
     every-sample evaluation (dc_speculative=0).  The last frames of the dongle-like streams run entirely in verified
-    blocks."""
+    blocks.  `per_step` blocks side by side (option dc_blocks_per_step: one wave each, totals exchanged through LDS; a step
+    that does not verify as a whole is taken again block by block): the same bits for every value."""
     di, dq, sigma = DC_STREAMS[stream]
     n = 384000
     t = tp.Topology(fs=1536000, frame=n, name="dcspec")
     t.vfos.append(tp.VfoDesc(topic="M", parent=-1, fs=1536000, decimate_count=3, mixer_freq=-496000.0, demod_usb=False, cstyle=1,
                              samples_per_buffer=n))
-    rx = Receiver.from_topology(t, exact=True)
-    rx0 = Receiver.from_topology(t, exact=True, dc_speculative=False)
+    rx = Receiver.from_topology(t, exact=True, dc_blocks_per_step=per_step)
+    rx0 = Receiver.from_topology(t, exact=True, dc_speculative=False) if per_step == 4 else None
     rng = np.random.default_rng(100 + sorted(DC_STREAMS).index(stream))
     state = np.zeros(2, np.float32)
-    prev = (0, 0)
+    prev = (0, 0, 0)
     for f in range(14):
         z = rng.standard_normal(2 * n) * sigma
         z[0::2] += di
@@ -944,24 +946,26 @@ def test_speculative_dc_chain_is_the_sequential_recurrence(Receiver, stream):
         iq = ob.u8_to_float(b)
         ob.dc_correct(iq, state)
         assert np.array_equal(bits(rx.raw()), bits(iq.view(np.complex64))), (stream, f, "vs the oracle")
-        if f % 4 == 3:
+        if rx0 is not None:
             rx0.process_u8(b, correct_dc=True)
-            assert np.array_equal(bits(rx0.raw()), bits(iq.view(np.complex64))), (stream, f, "every-sample evaluation vs the oracle")
-        else:
-            rx0.process_u8(b, correct_dc=True)
+            if f % 4 == 3:
+                assert np.array_equal(bits(rx0.raw()), bits(iq.view(np.complex64))), (stream, f, "every-sample evaluation vs the oracle")
         st = rx.stats()
-        blocks, fb = st["dc_blocks"] - prev[0], st["dc_fallback_blocks"] - prev[1]
-        prev = (st["dc_blocks"], st["dc_fallback_blocks"])
+        blocks, fb, again = st["dc_blocks"] - prev[0], st["dc_fallback_blocks"] - prev[1], st["dc_retried_blocks"] - prev[2]
+        prev = (st["dc_blocks"], st["dc_fallback_blocks"], st["dc_retried_blocks"])
         assert blocks == 2 * 375
+        assert again == 0 or per_step > 1
         if f == 13:
-            print(f"{stream}: frame 13 redid {fb} of {blocks} blocks sequentially; estimates {state}")
+            print(f"{stream}, {per_step} blocks per step: frame 13 redid {fb} of {blocks} blocks sequentially, took {again} again on their own; estimates {state}")
             if stream in ("offsets of the capture-like stream", "quiet front end", "strong carriers"):
                 assert fb <= blocks // 10, (stream, fb)
     rx.close()
-    rx0.close()
+    if rx0 is not None:
+        rx0.close()
 
 
-def test_speculative_dc_chain_on_constant_and_extreme_bytes(Receiver):
+@pytest.mark.parametrize("per_step", [1, 2, 4])
+def test_speculative_dc_chain_on_constant_and_extreme_bytes(Receiver, per_step):
     """All-255, all-0, all-127 and alternating 0 / 255 bytes, frames that are not a whole number of blocks (480 000 = 468.75
     blocks, 57 600): the accumulator runs up to +-128 through every binade on the way, `p` is one value (every block either
     verifies or is an exact tie), the last block is partial."""
@@ -969,7 +973,7 @@ def test_speculative_dc_chain_on_constant_and_extreme_bytes(Receiver):
         t = tp.Topology(fs=4 * n, frame=n, name=f"dcx{n}")
         t.vfos.append(tp.VfoDesc(topic="M", parent=-1, fs=4 * n, decimate_count=2, mixer_freq=float(n // 7), demod_usb=False, cstyle=1,
                                  samples_per_buffer=n))
-        rx = Receiver.from_topology(t, exact=True)
+        rx = Receiver.from_topology(t, exact=True, dc_blocks_per_step=per_step)
         state = np.zeros(2, np.float32)
         frames = []
         for val in (255, 0, 127):
