@@ -135,8 +135,10 @@ struct sdrx_ctx {
     // per-parity events below (measured on this runtime, tools/event_probe.hip: a record costs its
     // stream ~3-5 us, a wait on an event that completed long ago ~2.5 us, a tight hop ~11 us).
     hipStream_t own_stream = nullptr, stream = nullptr, tail_stream = nullptr, copy_stream = nullptr, copy_stream2 = nullptr;
+    int late_copy = -1;                    // payload copy issued by sdrx_wait instead of queued behind the frame: -1 = for frames that carry the DC recurrence, 0 never, 1 always (SDRX_LATE_COPY)
+    bool copy_owed[2] = {false, false};    //   ... and not issued yet
     bool upload_kernel = false; // SDRX_UPLOAD_KERNEL=1: host frames go up with k_copy16 instead of hipMemcpyAsync (A/B switch; slower)
-    int download_blocks = 64;   // workgroups of the payload copy kernel (SDRX_DOWNLOAD_BLOCKS; 0: always hipMemcpyAsync) ...
+    int download_blocks = 0;    // workgroups of a payload copy KERNEL for the frames that carry the recurrence (SDRX_DOWNLOAD_BLOCKS with SDRX_LATE_COPY=0; 0: hipMemcpyAsync) ...
     bool long_frame = false;    // ... which carries the payloads of frames whose kernels outlast the copy (the DC-bias recurrence)
     hipEvent_t ev_levels[2] = {nullptr, nullptr}; // levels of frame f done (recorded on `stream`)
     hipEvent_t ev_tail[2] = {nullptr, nullptr};   // tail of frame f done (recorded on the tail's stream)
@@ -383,16 +385,20 @@ int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode, bool egress)
         HIPCHK(c, hipEventRecord(c->ev_tail[p], ts));
         c->tail_recorded[p] = pipe;
     }
-    if (egress) {
+    // How the payloads leave (measured, traced: profiles/README.md round 5; tools/copy_overlap_probe.hip).  Normally queued here,
+    // behind the frame's last kernel: hipMemcpyAsync on a copy stream, which the runtime hands to an SDMA engine -- the kernels of
+    // the next frame run beside it, config 3 from host floats goes at PCIe speed (0.30 ms per pipelined frame = the 15 MB copy).
+    // A frame that carries the DC-bias recurrence did not get to run beside a copy queued that way (0.59-0.82 ms per frame,
+    // about the SUM of its parts), nor beside a copy kernel of ours (a kernel cannot retire beside one): for those frames the copy
+    // is issued by sdrx_wait, when the host has seen the frame's last kernel end -- 0.34 ms per frame.  (The float path would lose
+    // by that, 0.38 vs 0.30: between two waits the copy engine idles.)  SDRX_LATE_COPY=0 / 1: never / always.
+    if (egress && (c->late_copy == 1 || (c->late_copy < 0 && c->long_frame))) {
+        c->copy_owed[p] = true;
+        c->in_flight++;
+    } else if (egress) {
         hipStream_t cs = (p && c->copy_stream2) ? c->copy_stream2 : c->copy_stream;
         HIPCHK(c, hipStreamWaitEvent(cs, c->ev_tail[p], 0));
-        // How the payloads leave (measured, traced: profiles/README.md round 5).  hipMemcpyAsync moves a device-to-host copy with a
-        // copy KERNEL of the runtime's own (__amd_rocclr_copyBuffer), ~280 us for config 3's 15 MB at PCIe speed; the kernels of
-        // the next frame run beside it when they are short (config 3 from host floats: 0.30 ms per pipelined frame = the copy),
-        // but a frame that starts with the DC-bias recurrence (0.45 ms of kernels) did not start before that copy had ended --
-        // pipelined 0.85 ms per frame against 0.84 synchronous.  A copy kernel of our own on 64 workgroups behaves the other way
-        // round (0.79 ms with the recurrence, 0.41 without): each path gets the copy it is faster with.  SDRX_DOWNLOAD_BLOCKS=0:
-        // hipMemcpyAsync always; = n: n workgroups.
+        // (SDRX_DOWNLOAD_BLOCKS=n with SDRX_LATE_COPY=0: a copy kernel of ours on n workgroups for the frames that carry the recurrence -- A/B switch)
         if (c->download_blocks > 0 && c->long_frame) {
             const size_t n16 = (c->pay_bytes + 15) / 16; // (both buffers are allocated in whole 16-byte units)
             hipLaunchKernelGGL(k_copy16, dim3(c->download_blocks), dim3(256), 0, cs, reinterpret_cast<const uint4 *>(c->d_pay[p]),
@@ -641,6 +647,8 @@ int sdrx_create(sdrx_ctx **out, int device)
     c->stream = c->own_stream;
     bool ok = hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    if (getenv("SDRX_LATE_COPY"))
+        c->late_copy = atoi(getenv("SDRX_LATE_COPY")) != 0;
     c->upload_kernel = getenv("SDRX_UPLOAD_KERNEL") && atoi(getenv("SDRX_UPLOAD_KERNEL")) != 0;
     if (getenv("SDRX_DC_WAVES"))
         c->dc_waves = atoi(getenv("SDRX_DC_WAVES"));
@@ -1835,11 +1843,31 @@ int sdrx_in_flight(sdrx_ctx *c) { return c ? c->in_flight : SDRX_EINVAL; }
 } // extern "C"
 
 namespace {
+// the oldest undelivered frame's payload copy, if sdrx_wait is the one to issue it (enqueue_frame: frames that carry the DC
+// recurrence): the host waits for the frame's last kernel, then the copy goes out with nothing to wait for
+int start_owed_copy(sdrx_ctx *c)
+{
+    if (c->in_flight <= 0)
+        return SDRX_OK;
+    const int p = (int)((c->frame_no - (unsigned long long)c->in_flight) & 1ull);
+    if (!c->copy_owed[p])
+        return SDRX_OK;
+    c->copy_owed[p] = false;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t cs = (p && c->copy_stream2) ? c->copy_stream2 : c->copy_stream;
+    HIPCHK(c, hipEventSynchronize(c->ev_tail[p]));
+    HIPCHK(c, hipMemcpyAsync(c->h_pay[p], c->d_pay[p], c->pay_bytes, hipMemcpyDeviceToHost, cs));
+    HIPCHK(c, hipEventRecord(c->ev_copied[p], cs));
+    return SDRX_OK;
+}
 // the oldest undelivered frame's payloads are in host memory afterwards (slot returned); no callbacks
 int wait_frame(sdrx_ctx *c, int *slot)
 {
     if (c->in_flight <= 0)
         return fail(c, SDRX_ESTATE, "sdrx_wait: no submitted frame is in flight");
+    int rc = start_owed_copy(c);
+    if (rc)
+        return rc;
     HIPCHK(c, hipSetDevice(c->device));
     const unsigned long long f = c->frame_no - (unsigned long long)c->in_flight; // the oldest undelivered frame
     const int p = (int)(f & 1ull);

@@ -490,6 +490,14 @@ int sdrx_group_wait(sdrx_group *g)
         return SDRX_EINVAL;
     if (g->in_flight <= 0)
         return gfail(g, SDRX_ESTATE, "sdrx_group_wait: no submitted frame is in flight");
+    for (size_t k = 0; k < g->m.size(); ++k) // (copies that are sdrx_wait's to issue: all devices' first, then the waits)
+        if (g->m[k].c) {
+            const int rc = start_owed_copy(g->m[k].c);
+            if (rc) {
+                g->broken = true;
+                return member_fail(g, (int)k, rc);
+            }
+        }
     for (size_t k = 0; k < g->m.size(); ++k) {
         if (!g->m[k].c)
             continue;
