@@ -176,7 +176,9 @@ int sdrx_set_stream(sdrx_ctx *ctx, void *hip_stream);
  * sdrx_submit* enqueue one frame and return at once: host -> device copy of the frame (staged through
  * pinned memory of the library's own: `iq` is borrowed for the duration of the call only, like the
  * argument of sdrj::demodData), kernels, and the device -> host copy of that frame's payloads on a
- * copy stream -- which therefore overlaps the kernels of the next frame.  sdrx_wait delivers the
+ * copy stream -- which therefore overlaps the kernels of the next frame.  (Frames of sdrx_submit_u8 with correct_dc: that
+ * copy is issued by sdrx_wait instead, once the frame's kernels have ended -- measured, it is the order in which the next
+ * frame's DC recurrence and the copy do run side by side)  sdrx_wait delivers the
  * OLDEST frame not yet delivered: it blocks until that frame's payloads are in host memory, then
  * runs the publish callback for every leaf in the reference's order (= ZmqPublisher::publish per
  * leaf, vfo.cpp:426-453); afterwards sdrx_get_output serves that frame.  At most
