@@ -964,6 +964,18 @@ def test_speculative_dc_chain_is_the_sequential_recurrence(Receiver, stream, per
         rx0.close()
 
 
+def test_dc_blocks_per_step_takes_powers_of_two_up_to_eight(Receiver):
+    """Option dc_blocks_per_step = waves of the recurrence's workgroup: 1, 2, 4 or 8; anything else is SDRX_EINVAL and names
+    the choices; after sdrx_finalize it is SDRX_ESTATE like every option."""
+    from sdrreceiver_amd.receiver import SdrxError
+    for bad in (0, 3, 16, -1):
+        with pytest.raises(SdrxError) as e:
+            Receiver(dc_blocks_per_step=bad)
+        assert e.value.code == -1 and "1, 2, 4 or 8" in str(e.value), (bad, str(e.value))
+    for good in (1, 2, 4, 8):
+        Receiver(dc_blocks_per_step=good).close()
+
+
 @pytest.mark.parametrize("per_step", [1, 2, 4])
 def test_speculative_dc_chain_on_constant_and_extreme_bytes(Receiver, per_step):
     """All-255, all-0, all-127 and alternating 0 / 255 bytes, frames that are not a whole number of blocks (480 000 = 468.75
