@@ -7,6 +7,8 @@ pre-quantisation float ``usb*gain*32768``, int16 within +-1 LSB.  The library's 
 ("exact") arithmetic is held to the stricter bar of bit-identity with the -O2 oracle; the
 "fast" (FMA) arithmetic to the 1e-5 bar.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -962,6 +964,18 @@ def test_speculative_dc_chain_is_the_sequential_recurrence(Receiver, stream, per
     rx.close()
     if rx0 is not None:
         rx0.close()
+
+
+def test_dc_soak_of_random_regimes(Receiver):
+    """tests/dc_soak.py: random offsets (0 ... +-120 LSB), noise (sigma 0 ... 60 LSB; 0 = constant bytes), frame lengths with
+    partial last steps, 1 / 2 / 4 / 8 blocks per step, frames from the zero state with an offset step half way -- every
+    DC-corrected frame bit for bit the oracle's.  A dozen regimes here; 60 were run on the round's final build
+    (profiles/r05_experiments/dc_soak.txt)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "dc_soak.py"), "12", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "soak: passed" in r.stdout
 
 
 def test_dc_blocks_per_step_takes_powers_of_two_up_to_eight(Receiver):
