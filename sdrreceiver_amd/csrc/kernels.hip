@@ -546,12 +546,13 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
 // value (the integer recurrence itself) and looks at the gaps  g_l = start_l + tot_l - start_(l+1)  between a run's end and the
 // start the next lane assumed: all gaps zero = every lane started where its predecessor ended = the recurrence itself.
 // Otherwise the starts move by the solution u of  u_(l+1) = (1 + s_l) u_l + g_l,  u_0 = 0  (a scan of affine maps: DPP inside a
-// wave, the waves' composed maps through LDS), s_l = the lane's secant slope out of its last two evaluations (0 at first: then the
-// step is "every start := the sum of the totals before it").  With all slopes 0 that iteration needs as many rounds as there
-// are lanes whose runs come across T one after the other; an estimate hovering at T with small steps (a quiet front end) or
-// pinned to it (an offset many times the noise) has slopes near -1 -- every run forgets where it started -- and the plain sums
-// overshoot for dozens of rounds, where the affine step lands next to the answer at once.  Near T the first round evaluates a
-// second start value too ("the estimate stays where it is") to have slopes from the beginning.
+// wave, the waves' composed maps through LDS), s_l = the lane's secant slope out of its last two evaluations; in the first
+// round, when there is only one, -min(1, 16 / range) for a run that saw both sides of T (its 16 merge points are spread over
+// about the range it covered) and 0 otherwise.  With all slopes 0 the step is "every start := the sum of the totals before
+// it", and that iteration needs as many rounds as there are lanes whose runs come across T one after the other; an estimate
+// hovering at T with small steps (a quiet front end) or pinned to it (an offset many times the noise) has slopes near -1 --
+// every run forgets where it started -- and the plain sums overshoot for dozens of rounds, where the affine step lands next to
+// the answer (tools/dc_iteration_model.py: the iteration as a numpy model, rounds by noise level and waves per step).
 // Nothing here has to be exact except the evaluation: a block is only accepted in a round that found every gap zero, and then
 // VERIFIED (that round's runs all stayed inside the context, no tie).  NW = 1: no LDS, no barrier.
 // In: `acc` (uniform over the workgroup), the lane's 16 products `p`, nv = lanes of this wave that hold samples, last_wave = the
