@@ -443,6 +443,44 @@ def test_submit_u8_with_dc_correction(Receiver):
     rx.close()
 
 
+def test_payload_copies_issued_by_wait(Receiver):
+    """Frames that carry the DC recurrence get their payload copy issued by sdrx_wait, the others have
+    it queued at submit time: both kinds in one stream of frames, two in flight, an sdrx_sync between submit and wait (the
+    copy is still owed afterwards), a synchronous frame after the queue has drained, and a context destroyed with frames in
+    flight -- payloads as the oracle's for every delivered frame."""
+    topo = tp.config2()
+    rx = Receiver.from_topology(topo)
+    nodes, roots = ob.build_tree("port", topo)
+    order = topo.leaves_in_publish_order()
+    rng = np.random.default_rng(19)
+    state = np.zeros(2, np.float32)
+    kinds = [True, True, False, True, False, False, True, True, True]  # correct_dc per frame
+    frames, want = [], []
+    for dc in kinds:
+        b = rng.integers(0, 256, 2 * topo.frame, dtype=np.uint8)
+        b[0::2] = np.clip(b[0::2].astype(int) // 8 + 100, 0, 255)
+        iq = ob.u8_to_float(b)
+        if dc:
+            ob.dc_correct(iq, state)
+        ob.process_roots(roots, iq)
+        frames.append(b)
+        want.append([nodes[i].usb().tobytes() for i in order])
+    rx.submit_u8(frames[0], correct_dc=kinds[0])
+    for f in range(1, 6):
+        rx.submit_u8(frames[f], correct_dc=kinds[f])
+        if f % 2:
+            rx.sync()  # everything queued has run; a copy that is sdrx_wait's to issue has not been issued
+        rx.wait()
+        assert [p for _, _, p in rx.published] == want[f - 1], f - 1
+    rx.wait()
+    assert [p for _, _, p in rx.published] == want[5]
+    rx.process_u8(frames[6], correct_dc=kinds[6])
+    assert [p for _, _, p in rx.published] == want[6]
+    rx.submit_u8(frames[7], correct_dc=kinds[7])
+    rx.submit_u8(frames[8], correct_dc=kinds[8])
+    rx.close()  # two frames in flight, both copies still owed
+
+
 def test_publish_order_and_framing(Receiver):
     """Callback order = main order x sub order (sdrj.cpp:288-294, vfo.cpp:257-263); topic is
     exactly 5 bytes, rate is outputRate, payload is the int16 audio (zmqpublisher.cpp:82-96)."""
