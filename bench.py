@@ -658,6 +658,14 @@ def main():
         abi["u8_dc_blocks"] = {"walked": int(st1["dc_blocks"] - st0["dc_blocks"]), "redone_sequentially": int(st1["dc_fallback_blocks"] - st0["dc_fallback_blocks"]),
                                "taken_again_on_their_own": int(st1["dc_retried_blocks"] - st0["dc_retried_blocks"]),
                                "input": "capture-like stream (offsets +1.3 / -0.7 LSB), frames 8-23 of the run"}
+        # the three kernels of the DC-bias removal alone (k_dc_products + k_dc_chain_spec + k_dc_apply), HIP events around the group
+        rx.enable_kernel_timing(True)
+        for b_ in cap:
+            rx.process_u8(b_, correct_dc=True)
+        kt_dc = rx.kernel_times().get("k_ingest")
+        rx.enable_kernel_timing(False)
+        if kt_dc and kt_dc["launches"]:
+            abi["u8_dc_kernels_ms"] = round(kt_dc["ms"] / kt_dc["launches"], 4)
         u8z = (job.frames_np[0] + 127).astype(np.uint8)
         rx.process_u8(u8z, correct_dc=True)
         barrier()
