@@ -2,8 +2,8 @@
 """bench.py -- throughput of the per-VFO IQ chain on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R]
-                    [--workload config3|flat|config2|config4|config5|10k|64k|256k|512k]
-                    [--fast] [--no-cpu] [--no-abi] [--configs1] [--batch B]
+                    [--workload config3|flat|flat10k|config2|config4|config5|10k|64k|256k|512k]
+                    [--fast] [--full] [--budget-s S] [--no-cpu] [--no-abi] [--configs1] [--batch B]
 
 A "step" is one pass of the hot path over one raw IQ frame (250 ms of signal: 384 000 cf32 at
 1.536 MS/s), already resident in HBM, through every VFO of the workload.
@@ -19,12 +19,19 @@ overrides the default (with `--workload config5` the roles swap: side object `we
 
 Timing.  W untimed warm-up steps (plus enough extra to reach ~50 ms of GPU time: the clock ramps),
 then the timed region -- EXACTLY K steps between barrier + torch.cuda.synchronize() on both sides,
-max over ranks -- is repeated R times (default 25); `ms_per_step` and `value` are the MEDIAN
+max over ranks -- is repeated R times (default 11); `ms_per_step` and `value` are the MEDIAN
 repetition, min / max are in `ms_per_step_min/max`.
 
-Prints ONE JSON line (rank 0).  `value` = IQ MSamples/s ingested, summed over every VFO chain of
-every rank (the unit that scales with the number of VFOs); `raw_iq_msps` and `vfos_at_realtime`
-are the other two readings of BASELINE.json's metric.
+Prints ONE JSON line of at most 8 KB (rank 0): the contract keys, `roofline`, `cpu_baseline`, `verified` and one compact
+row per side workload.  Everything else that is measured (the counters' VALU sub-objects, the instruction mix, the
+through-the-ABI details, the prose) goes to `bench_full.json` beside this file (and to `gpurun_out/` where that exists) and
+to stderr.  `value` = IQ MSamples/s ingested, summed over every VFO chain of every rank (the unit that scales with the
+number of VFOs); `raw_iq_msps` and `vfos_at_realtime` are the other two readings of BASELINE.json's metric.
+
+Time.  The default command is held to ~30 s of wall time (`--budget-s`): the clock is warmed on a throw-away receiver, so
+the oracle that verifies the timed launch sequence replays a few hundred frames, not a thousand; the side workloads run in
+order of importance while the budget lasts (a side that did not fit says so in its row); `--full` lifts the budget and
+adds the Qt drop-in legs.
 """
 from __future__ import annotations
 
@@ -50,6 +57,9 @@ def make_topology(name, world):
         return tp.config3(1024 * world), "BASELINE config 3: 2 main VFOs (1.536 MS/s -> 384 k / 192 k) + 1024 sub VFOs per GPU"
     if name == "flat":
         return tp.config3_flat(1024 * world), "flat variant: 1024 leaf VFOs per GPU, each 1.536 MS/s -> 48 kHz (d=5)"
+    if name == "flat10k":
+        return tp.config3_flat(10240 * world), ("the north-star sentence read literally: 10 240 leaf VFOs per GPU, EACH consuming the 1.536 MS/s "
+                                                "stream (1.536 MS/s -> 48 kHz, d=5, no parent)")
     if name == "config2":
         return tp.config2(), "BASELINE config 2: 32 sub VFOs across the 2 sdr_25E main VFOs"
     if name == "config4":
@@ -77,14 +87,14 @@ def cpu_baseline(workload):
     "port").  The all-cores OpenMP figure of the port is reported next to it."""
     from oracle import binding as ob
     from sdrreceiver_amd import synth, topology as tp
-    if workload == "flat":
-        topo, frames = tp.config3_flat(16), 8
+    if workload in ("flat", "flat10k"):
+        topo, frames = tp.config3_flat(8), 8
     elif workload == "config4":
-        topo, frames = tp.config4(96), 12
+        topo, frames = tp.config4(48), 12
     elif workload == "config2":
-        topo, frames = tp.config2(), 40
+        topo, frames = tp.config2(), 20
     else:
-        topo, frames = tp.config3(256), 12
+        topo, frames = tp.config3(128), 24   # ~230 M VFO-samples: ~4.5 s of the reference's one thread (+ ~2 s for the port's two readings)
     sample = f"{topo.name}: {len(topo.vfos)} VFOs x {frames} frames of {topo.frame} cf32 (LCG input)"
     iq = synth.lcg_frame(topo.frame, synth.Lcg(1))
     out = {}
@@ -332,23 +342,117 @@ def roofline_object(dom, d, kt_steps, frame_kernel_ms, alg_bytes, world, pm, mix
     return r
 
 
+ROOFLINE_LINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_GBps",
+                      "algorithmic_over_hbm_peak", "frac_hbm_unique", "bytes_per_launch", "avg_launch_ms", "frame_kernel_ms", "frame_frac",
+                      "l2_hit_rate", "pmc_build_id", "pmc_matches_build")
+SIDE_KEYS = ("north_star_10k", "flat_10k", "flat_1024", "config4_256", "fast_config3", "fast_10k", "fast_config4", "robust_config3",
+             "robust_10k", "robust_config4", "config5_64k_one_gpu", "config5_strong", "weak_config3", "configs1_32_sub_vfos")
+LINE_LIMIT = 8192  # bytes: what the driver's parser is known to take (the 22.7 KB line of round 5 was not parsed)
+
+
+def side_row(o):
+    """One compact row of a side workload for the printed line (its whole object is in bench_full.json)."""
+    if not isinstance(o, dict):
+        return o
+    if "ms_per_step" not in o:
+        return {k: o[k] for k in ("skipped", "error") if k in o}
+    r = {"ms_per_step": o["ms_per_step"]}
+    for k in ("sub_vfos", "sub_vfos_total", "realtime_factor", "frame_frac", "scaling", "value"):
+        if k in o:
+            r[k] = o[k]
+    if "arithmetic" in o:
+        r["arithmetic"] = o["arithmetic"].split(" ", 1)[0]
+    rf = o.get("roofline") or {}
+    if rf:
+        r["bound"], r["frac"] = rf.get("bound"), rf.get("frac")
+    if isinstance(o.get("verified"), dict):
+        r["verified_ok"] = o["verified"].get("ok")
+        if "worst_stream_rel_err" in o["verified"]:
+            r["worst_rel_err"] = o["verified"]["worst_stream_rel_err"]
+    return r
+
+
+def compact_line(full, limit=LINE_LIMIT):
+    """The printed line: the contract keys + roofline + cpu_baseline + verified + one row per side workload, <= `limit`
+    bytes.  Optional parts are dropped (least important first) should it ever come out longer."""
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_min", "ms_per_step_max",
+                                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "build_id", "repetitions", "raw_iq_msps",
+                                 "vfos_at_realtime", "realtime_factor", "algorithmic_GBps_whole_frame", "frame_frac_of_hbm_roofline",
+                                 "ms_per_step_through_abi", "ms_per_step_with_payload_d2h", "rccl_world", "peer_ok", "wall_s") if k in full}
+    c = full.get("config", {})
+    clip = lambda x: (x[:297] + "...") if isinstance(x, str) and len(x) > 300 else x   # noqa: E731  (prose never decides the line's size)
+    line["config"] = {k: clip(c[k]) for k in ("workload", "name", "arithmetic", "vfos_total", "sub_vfos_per_gpu", "parallelism") if k in c}
+    if "roofline" in full:
+        line["roofline"] = {k: full["roofline"][k] for k in ROOFLINE_LINE_KEYS if k in full["roofline"]}
+        v = full["roofline"].get("valu")
+        if v:
+            line["roofline"]["valu_busy"] = v.get("busy")
+            if "useful_frac" in v:
+                line["roofline"]["valu_useful_frac"] = v["useful_frac"]
+    if "cpu_baseline" in full:
+        line["cpu_baseline"] = {k: clip(v) for k, v in full["cpu_baseline"].items()}
+    if isinstance(full.get("verified"), dict):
+        line["verified"] = {k: full["verified"][k] for k in ("ok", "leaves", "frames", "checkpoints", "error", "ranks_with_mismatches", "worst_stream_rel_err")
+                            if k in full["verified"]}
+    if "kernels" in full:
+        line["kernels"] = {k: {"avg_ms": v["avg_ms"]} for k, v in full["kernels"].items()}
+    a = full.get("through_abi")
+    if a:
+        t = {k: a[k] for k in ("sync_pageable_ms", "pipelined_pageable_ms", "pipelined_u8_ms", "u8_dc_sync_ms", "u8_dc_pipelined_ms", "u8_dc_kernels_ms")
+             if k in a}
+        if isinstance(a.get("c_host"), dict):
+            t["c_host"] = {k: v for k, v in a["c_host"].items() if k.endswith("_ms") or k == "error"}
+        if isinstance(a.get("qt_adapter"), dict):
+            t["qt_adapter"] = {k: v for k, v in a["qt_adapter"].items() if k.endswith("_ms")}
+        line["through_abi"] = t
+    for k in SIDE_KEYS:
+        if k in full:
+            line[k] = side_row(full[k])
+    line["full"] = "bench_full.json"
+    for drop in ("kernels", "through_abi", "raw_iq_msps", "repetitions", "algorithmic_GBps_whole_frame") + tuple(reversed(SIDE_KEYS)):
+        if len(json.dumps(line)) <= limit:
+            break
+        line.pop(drop, None)
+    return line
+
+
+def write_full(full):
+    """Everything that was measured: bench_full.json beside this file (+ gpurun_out/, which travels back from the GPU box)
+    and stderr.  Never stdout: the driver reads ONE line there."""
+    text = json.dumps(full, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    f.write(text + "\n")
+            except OSError:
+                pass
+    print("bench_full: " + json.dumps(full), file=sys.stderr)
+
+
 def main():
+    t_start = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--reps", type=int, default=25, help="repetitions of the timed K-step region (median reported)")
+    ap.add_argument("--reps", type=int, default=0, help="repetitions of the timed K-step region (median reported; default 11, 25 with --full)")
     ap.add_argument("--workload", default=None)
     ap.add_argument("--fast", action="store_true",
                     help="the tolerance arithmetic (option exact = 0: within 1e-5 of the reference, north_star's bar) instead of bit-exact")
+    ap.add_argument("--full", action="store_true",
+                    help="no time budget: every side workload, 25 repetitions, a larger oracle sample, the Qt drop-in legs")
+    ap.add_argument("--budget-s", type=float, default=30.0,
+                    help="wall-time budget of the default command: side workloads are started only while it lasts")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-abi", action="store_true", help="skip the through-the-ABI (host buffers, PCIe both ways) leg")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the oracle check of the timed launch sequence (`verified` in the line; a profiled command skips it: "
                          "the checkpoints add fetches and single-level launches to the kernel statistics)")
     ap.add_argument("--no-side", action="store_true",
-                    help="skip the side readings of the N = 1 line (north-star 10 240 subs, flat 1 024, config 4): a profiled "
+                    help="skip the side readings of the N = 1 line (north-star 10 240 subs, flat, config 4, ...): a profiled "
                          "command must launch the kernels of ONE workload only")
+    ap.add_argument("--no-clock-warmup", action="store_true", help="no throw-away receiver spinning the clock up before the timed regions")
     ap.add_argument("--pipeline", action="store_true", help="leaf tail on a second stream beside the next frame's levels (A/B switch; slower)")
     ap.add_argument("--no-fuse", action="store_true", help="one k_mix_decimate launch per tree level instead of k_mix_levels (A/B switch)")
     ap.add_argument("--no-frame-pipeline", action="store_true", help="k_mix_levels, but every frame runs through all its levels at once (A/B switch)")
@@ -358,6 +462,22 @@ def main():
                     help="also time BASELINE configs[1] (32 sub VFOs) and report it as a side reading (off by default: the "
                          "profiled default command must launch the kernels of ONE workload only)")
     args = ap.parse_args()
+    n_reps = args.reps or (25 if args.full else 11)
+    budget = float("inf") if args.full else args.budget_s
+    legs = {}  # wall seconds per leg of the run (bench_full.json): where the command's time goes
+
+    def left():
+        return budget - (time.perf_counter() - t_start)
+
+    class leg:
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            self.t0 = time.perf_counter()
+
+        def __exit__(self, *a):
+            legs[self.name] = round(legs.get(self.name, 0.0) + time.perf_counter() - self.t0, 2)
 
     import numpy as np
     import torch
@@ -388,6 +508,7 @@ def main():
     stream = torch.cuda.Stream()  # a real (non-null) stream shared by torch, RCCL ordering and our kernels
     torch.cuda.set_stream(stream)
     batch = args.batch or (4 if use_dist else 1)
+    legs["start_up"] = round(time.perf_counter() - t_start, 2)
 
     def barrier():
         torch.cuda.synchronize()
@@ -409,17 +530,80 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return [float(x) for x in t.tolist()]
 
+    diag_world, diag_peer = None, None
+    if use_dist:
+        # so that the first run on several devices diagnoses itself: what the process group says, who reaches whom
+        diag_world = dist.get_world_size()
+        try:
+            ok = 1 if (local == 0 or share) else int(torch.cuda.can_device_access_peer(local, 0))
+        except Exception:
+            ok = -1
+        if os.environ.get("SDRX_BENCH_FAKE_NO_PEER") == "1" and rank == world - 1:
+            ok = 0  # (tests/test_distributed_gpu.py: what the refusal below looks like, on a box where every rank reaches rank 0)
+        t = torch.zeros(world, dtype=torch.int64, device="cuda")
+        t[rank] = ok
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        diag_peer = [int(x) for x in t.tolist()]
+        if (diag_world != args.gpus or 0 in diag_peer) and os.environ.get("SDRX_BENCH_ALLOW_NO_PEER") != "1":
+            # a run whose ranks cannot reach rank 0's device directly (the broadcast would be staged through the host) or whose
+            # process group is not the one asked for measures the wrong thing: say why and fail instead of printing a slow number
+            if rank == 0:
+                print(f"bench: refusing to measure: --gpus {args.gpus} but the process group has {diag_world} ranks; "
+                      f"hipDeviceCanAccessPeer(rank's device -> rank 0's device) per rank = {diag_peer} (0 = no direct xGMI / PCIe peer "
+                      "access: the raw-frame broadcast would go through host memory).  Check HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES, "
+                      "the IOMMU / ACS settings and `rocm-smi --showtopo`; SDRX_BENCH_ALLOW_NO_PEER=1 measures anyway.", file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(4)
+
+    class ClockWarmer:
+        """Spins the clock up before a timed region: ~50 ms of the same kernels on a throw-away receiver (config 3, 1 024 subs)
+        that nothing verifies -- a cold 5 ms measurement reads 0.137 ms per frame where the warm one reads 0.110.
+        Kept apart from the measured receivers so that the oracle, which replays EVERY frame a measured receiver was handed,
+        replays a few hundred frames instead of a thousand."""
+
+        def __init__(self):
+            self.rx, self.per_step = None, None
+            if args.no_clock_warmup:
+                return
+            t = tp.config3(1024)
+            self.rx = Receiver.from_topology(t, device=local, exact=not args.fast)
+            self.rx.set_stream(stream.cuda_stream)
+            self.frame = t.frame
+            self.src = torch.from_numpy(synth.lcg_frame(t.frame, synth.Lcg(7))).to(dev)
+
+        def spin(self, seconds=0.05):
+            if not self.rx:
+                return
+            if self.per_step is None:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(40):
+                    self.rx.process_device(self.src.data_ptr(), self.frame)
+                torch.cuda.synchronize()
+                self.per_step = max((time.perf_counter() - t0) / 40, 2e-5)
+            for _ in range(int(min(4000, seconds / self.per_step))):
+                self.rx.process_device(self.src.data_ptr(), self.frame)
+
+        def close(self):
+            if self.rx:
+                torch.cuda.synchronize()
+                self.rx.close()
+                self.rx = None
+
+    with leg("clock_warmer"):
+        warmer = ClockWarmer()
+
     class Job:
         """One workload on this rank's shard: the Receiver, the raw-frame source and the broadcast."""
 
-        def __init__(self, name, exact=None):
+        def __init__(self, name, exact=None, options=None):
             self.exact = (not args.fast) if exact is None else bool(exact)
             self.full, self.descr = make_topology(name, world)
             self.topo = tp.shard(self.full, rank, world)
             self.frame = self.full.frame
             self.rx = Receiver.from_topology(self.topo, device=local, exact=self.exact, segments=args.segments,
                                              pipeline=args.pipeline, fuse=not args.no_fuse,
-                                             frame_pipeline=not args.no_frame_pipeline) if self.topo.vfos else None
+                                             frame_pipeline=not args.no_frame_pipeline, **(options or {})) if self.topo.vfos else None
             if self.rx:
                 self.rx.set_stream(stream.cuda_stream)
             self.st = self.rx.stats() if self.rx else {"vfo_samples_per_frame": 0, "algorithmic_bytes_per_frame": 0, "n_leaves": 0,
@@ -464,12 +648,14 @@ def main():
             for k in range(warmup):
                 self.step(k)
             self.realign(warmup)
-            dt = self.timed(steps)          # also tells how many more warm-up steps make ~50 ms of GPU time
-            self.realign(steps)
-            extra = int(min(2000, max(0, 0.05 / max(dt / steps, 1e-7) - steps - warmup)))
-            for k in range(extra):
-                self.step(k)
-            self.realign(extra)
+            warmer.spin()                   # the clock: ~50 ms of GPU time on the throw-away receiver, queued in front of the region
+            if args.no_clock_warmup:        # (A/B: the round-5 way, warm-up frames through the measured receiver itself)
+                dt = self.timed(steps)
+                self.realign(steps)
+                extra = int(min(2000, max(0, 0.05 / max(dt / steps, 1e-7) - steps - warmup)))
+                for k in range(extra):
+                    self.step(k)
+                self.realign(extra)
             out = []
             for _ in range(reps):
                 out.append(self.timed(steps))
@@ -520,15 +706,18 @@ def main():
                 dom, dom_ms = name, per_frame
         return kt, kernels, dom, frame_kernel_ms
 
-    def side_reading(name, exact=None):
+    def side_reading(key, name, exact=None, need_s=3.0, options=None):
         """Another workload of BASELINE.json / SURVEY.md 8d on this GPU (or the default one in the other arithmetic),
         measured the same way (clock warm-up, K steps between synchronisations, median of a few repetitions, event-timed
         kernel pass, oracle check of the timed launch sequence): a side object of the N = 1 line.  `value` and
-        `ms_per_step` of the line stay those of the default workload."""
+        `ms_per_step` of the line stay those of the default workload.  Started only while the command's time budget lasts."""
+        if left() < need_s:
+            return {"skipped": f"time budget ({budget:g} s; --full runs it)"}
+        t_side = time.perf_counter()
         try:
-            j = Job(name, exact)
-            sv = Verifier(j, n_random=32) if (j.rx and not args.no_verify) else None
-            sreps = j.measure(args.steps, args.warmup, max(1, min(args.reps, 5)), sv)
+            j = Job(name, exact, options)
+            sv = Verifier(j, n_random=32 if args.full else 0) if (j.rx and not args.no_verify) else None
+            sreps = j.measure(args.steps, args.warmup, 5 if args.full else 3, sv)
             sdt = statistics.median(sreps)
             ks = min(args.steps, 12)
             skt, skern, sdom, sfk = kernel_pass(j, ks)
@@ -542,6 +731,8 @@ def main():
                  "vfos_at_realtime": int(j.st["n_leaves"] * fsec / (sdt / args.steps)),
                  "algorithmic_GBps_whole_frame": round(args.steps * j.st["algorithmic_bytes_per_frame"] / sdt / 1e9, 1),
                  "frame_frac": round(args.steps * j.st["algorithmic_bytes_per_frame"] / sdt / 1e9 / HBM_PEAK_GBS, 4)}
+            if options:
+                o["options"] = options
             if sdom:
                 o["roofline"] = roofline_object(sdom, skt[sdom], ks, sfk, j.st["algorithmic_bytes_per_frame"], 1,
                                                 pmc_for(name, j.exact), j.st["mix_chunks_per_frame"], demanded_valu_per_launch(j.topo, j.exact))
@@ -555,45 +746,49 @@ def main():
             return o
         except Exception as e:  # the bench line must still come out
             return {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            legs["side:" + key] = round(time.perf_counter() - t_side, 2)
 
-    diag_world, diag_peer = None, None
-    if use_dist:
-        # so that the first run on several devices diagnoses itself: what the process group says, who reaches whom
-        diag_world = dist.get_world_size()
-        try:
-            ok = 1 if (local == 0 or share) else int(torch.cuda.can_device_access_peer(local, 0))
-        except Exception:
-            ok = -1
-        t = torch.zeros(world, dtype=torch.int64, device="cuda")
-        t[rank] = ok
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        diag_peer = [int(x) for x in t.tolist()]
-
-    job = Job(workload)
+    with leg("main_job_create"):
+        job = Job(workload)
     topo, rx, st, full, descr = job.topo, job.rx, job.st, job.full, job.descr
-    ver = Verifier(job) if (rx and not args.no_verify) else None
-    reps = job.measure(args.steps, args.warmup, max(1, args.reps), ver)
+    ver = Verifier(job, n_random=64 if args.full else 32) if (rx and not args.no_verify) else None
+    with leg("main_measure"):
+        reps = job.measure(args.steps, args.warmup, max(1, n_reps), ver)
     dt = statistics.median(reps)
     vfo_samples, alg_bytes, n_leaves = allsum([st["vfo_samples_per_frame"], st["algorithmic_bytes_per_frame"], st["n_leaves"]])
 
     kt_steps = min(args.steps, 20)
-    kt, kernels, dom, frame_kernel_ms = kernel_pass(job, kt_steps)
+    with leg("kernel_pass"):
+        kt, kernels, dom, frame_kernel_ms = kernel_pass(job, kt_steps)
     verified = None
     if ver:
-        ver.checkpoint(with_streams=True)
-        try:  # (the oracle runs here, on the host, before the legs below put other frames through this receiver)
-            verified = ver.finish(exact=not args.fast)
-        except Exception as e:
-            verified = {"ok": None, "error": f"{type(e).__name__}: {e}"}
+        with leg("main_verify"):
+            ver.checkpoint(with_streams=True)
+            try:  # (the oracle runs here, on the host, before the legs below put other frames through this receiver)
+                verified = ver.finish(exact=not args.fast)
+            except Exception as e:
+                verified = {"ok": None, "error": f"{type(e).__name__}: {e}"}
     if use_dist:  # every rank checks its own shard; the line reports the worst
         nbad = allsum([0.0 if (verified is None or verified.get("ok")) else 1.0])[0]
         if verified is not None and nbad:
             verified["ok"] = False
             verified["ranks_with_mismatches"] = int(nbad)
 
+    # the reference's CPU path on this box's host cores, rank 0 at N = 1 (before the side workloads: it is part of the contract,
+    # they are not)
+    cpu = None
+    if world == 1 and not args.no_cpu:
+        with leg("cpu_baseline"):
+            try:
+                cpu = cpu_baseline(workload)
+            except Exception as e:  # the bench line must still come out
+                cpu = {"error": f"{type(e).__name__}: {e}"}
+
     # third (N = 1): through the C ABI from HOST buffers -- what a Qt / C++ host sees, PCIe both ways.
     abi = None
     if world == 1 and not args.no_abi and rx:
+        t_abi = time.perf_counter()
         n_abi = max(8, min(args.steps, 24))
         pay_mb = sum(topo.vfos[i].n_out * 2 if topo.vfos[i].demod_usb else topo.vfos[i].n_stage_out
                      for i in topo.leaves_in_publish_order()) / 1e6
@@ -689,36 +884,45 @@ def main():
                 abi["c_host"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-300:]}
             except Exception as e:
                 abi["c_host"] = {"error": f"{type(e).__name__}: {e}"}
+        legs["through_abi"] = round(time.perf_counter() - t_abi, 2)
 
     side = {}
     if world == 1 and workload == "config3" and not args.no_side:
-        # BASELINE.json's north-star target, SURVEY.md 8d's flat variant ("1.536 MS/s -> 48 kHz chain" read literally)
-        # and config 4, on this same box and build -- side objects; a few hundred ms of GPU time each
-        for key, name in (("north_star_10k", "10k"), ("flat_1024", "flat"), ("config4_256", "config4")):
-            side[key] = side_reading(name)
+        # In order of importance (the time budget may cut the list short): BASELINE.json's north-star target, the same workload in
+        # the TOLERANCE arithmetic north_star allows ("within 1e-5 relative float tolerance"; option exact = 0; each checked against
+        # the oracle at that tolerance), config 4, the north-star sentence read literally (10 240 flat leaves at 1.536 MS/s),
+        # SURVEY.md 8d's flat variant of config 3, and BASELINE config 5's whole tree (65 536 sub VFOs) on this ONE GPU: the N = 1
+        # origin of the strong-scaling curve the N > 1 lines carry as `config5_strong`.  (key, workload, exact, seconds it needs)
+        plan = [("north_star_10k", "10k", None, 4.0)]
         if not args.fast:
-            # what exactness costs: the same workloads in the TOLERANCE arithmetic north_star allows ("within 1e-5 relative
-            # float tolerance"; option exact = 0), each checked against the oracle at that tolerance
-            for key, name in (("fast_config3", "config3"), ("fast_10k", "10k"), ("fast_config4", "config4")):
-                side[key] = side_reading(name, exact=False)
-        # BASELINE config 5's whole tree (65 536 sub VFOs) on this ONE GPU: the N = 1 origin of the strong-scaling curve the
-        # N > 1 lines carry as `config5_strong` (65 536 / N sub VFOs per GPU)
-        side["config5_64k_one_gpu"] = side_reading("64k")
+            plan.append(("fast_config3", "config3", False, 2.5))
+        plan += [("config4_256", "config4", None, 2.5), ("flat_10k", "flat10k", None, 6.0)]
+        if not args.fast:
+            plan += [("fast_10k", "10k", False, 4.0), ("fast_config4", "config4", False, 2.5)]
+        plan += [("flat_1024", "flat", None, 3.0), ("config5_64k_one_gpu", "64k", None, 9.0)]
+        for key, name, ex, need in plan:
+            side[key] = side_reading(key, name, exact=ex, need_s=need)
 
-    # fourth (N = 1): the Qt drop-in -- `class vfo` of the reference's unmodified vfo.h over the adapter
+    # fourth (N = 1, --full): the Qt drop-in -- `class vfo` of the reference's unmodified vfo.h over the adapter
     # (host/qt/vfo_adapter.cpp), driven like sdrj::demodData drives it, transmitData / ZmqPublisher::publish included
     if abi is not None and workload == "config3" and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdropin_sdrx.so")):
         import subprocess
         qt = {}
-        for label, env in (("sync", {}), ("sync_shared_upload", {"SDRX_SHARE_UPLOAD": "1"}), ("pipelined", {"SDRX_PIPELINE": "1"})):
-            try:
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dropin_run.py"), "time", "sdrx", "1024", "12"],
-                                   capture_output=True, text=True, timeout=300, env=dict(os.environ, SDRX_DEVICE=str(local), **env))
-                qt[label + "_ms"] = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_frame"] if r.returncode == 0 else {"error": r.stderr[-300:]}
-            except Exception as e:
-                qt[label + "_ms"] = {"error": f"{type(e).__name__}: {e}"}
+        modes = (("sync", {}), ("sync_shared_upload", {"SDRX_SHARE_UPLOAD": "1"}), ("pipelined", {"SDRX_PIPELINE": "1"})) if args.full else \
+                (("pipelined", {"SDRX_PIPELINE": "1"}), ("sync", {}))
+        with leg("qt_adapter"):
+            for label, env in modes:
+                if left() < 4.0:
+                    qt[label + "_ms"] = None
+                    continue
+                try:
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dropin_run.py"), "time", "sdrx", "1024", "12"],
+                                       capture_output=True, text=True, timeout=300, env=dict(os.environ, SDRX_DEVICE=str(local), **env))
+                    qt[label + "_ms"] = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_frame"] if r.returncode == 0 else {"error": r.stderr[-300:]}
+                except Exception as e:
+                    qt[label + "_ms"] = {"error": f"{type(e).__name__}: {e}"}
         qt["note"] = ("per frame: process() on both main VFOs of config 3 through the public interface of vfo.h, 1024 x (payload copy into "
-                      "transmit_usb + ZmqPublisher::publish) included; one context per main VFO")
+                      "transmit_usb + ZmqPublisher::publish) included; one context per main VFO; null = did not fit the time budget (--full)")
         abi["qt_adapter"] = qt
 
     weak, other_key = None, None
@@ -729,18 +933,19 @@ def main():
                                            ("config3", "weak_config3", "weak"))
         job.close()
         job = None
-        try:
-            wj = Job(other)
-            wreps = wj.measure(args.steps, args.warmup, max(1, min(args.reps, 7)))
-            wdt = statistics.median(wreps)
-            ws, wa, wl = allsum([wj.st["vfo_samples_per_frame"], wj.st["algorithmic_bytes_per_frame"], wj.st["n_leaves"]])
-            weak = {"workload": wj.descr, "scaling": other_scaling, "ms_per_step": round(wdt / args.steps * 1e3, 4),
-                    "value": round(args.steps * ws / wdt / 1e6, 2), "unit": "MSamples/s",
-                    "realtime_factor": round((wj.full.frame / wj.full.fs) / (wdt / args.steps), 1),
-                    "algorithmic_GBps_whole_job": round(args.steps * wa / wdt / 1e9, 1), "sub_vfos_total": int(wl)}
-            wj.close()
-        except Exception as e:
-            weak = {"error": f"{type(e).__name__}: {e}"}
+        with leg("side:" + other_key):
+            try:
+                wj = Job(other)
+                wreps = wj.measure(args.steps, args.warmup, 7 if args.full else 5)
+                wdt = statistics.median(wreps)
+                ws, wa, wl = allsum([wj.st["vfo_samples_per_frame"], wj.st["algorithmic_bytes_per_frame"], wj.st["n_leaves"]])
+                weak = {"workload": wj.descr, "scaling": other_scaling, "ms_per_step": round(wdt / args.steps * 1e3, 4),
+                        "value": round(args.steps * ws / wdt / 1e6, 2), "unit": "MSamples/s",
+                        "realtime_factor": round((wj.full.frame / wj.full.fs) / (wdt / args.steps), 1),
+                        "algorithmic_GBps_whole_job": round(args.steps * wa / wdt / 1e9, 1), "sub_vfos_total": int(wl)}
+                wj.close()
+            except Exception as e:
+                weak = {"error": f"{type(e).__name__}: {e}"}
 
     failed = []
     if rank == 0:
@@ -813,14 +1018,15 @@ def main():
                                                "algorithmic_GBps_whole_frame": round(st2["algorithmic_bytes_per_frame"] / d2 / 1e9, 1)}
             except Exception as e:
                 out["configs1_32_sub_vfos"] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and not args.no_cpu:
-            try:
-                out["cpu_baseline"] = cpu_baseline(workload)
-            except Exception as e:  # the bench line must still come out
-                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
-        print(json.dumps(out))
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        out["legs_s"] = legs
+        out["wall_s"] = round(time.perf_counter() - t_start, 1)
+        write_full(out)
+        print(json.dumps(compact_line(out)), flush=True)
         failed = [k for k, v in [("", out)] + [(k, v) for k, v in out.items() if isinstance(v, dict)]
                   if isinstance(v.get("verified"), dict) and v["verified"].get("ok") is False]
+    warmer.close()
     if job:
         job.close()
     if use_dist:

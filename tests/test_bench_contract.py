@@ -89,29 +89,74 @@ def test_no_committed_kernel_reads_more_than_fully_busy():
                 assert 0.0 <= e["valu"].get("valu_busy", e["valu"]["valu_busy_raw"]) <= 1.0, (f, k)
 
 
+def test_printed_line_stays_under_8_kb():
+    """the driver could not parse the 22.7 KB line of round 5.  `compact_line` turns everything a run
+    measures (here: that very line, committed as profiles/r05/bench_default_with_cpu_baseline.json) into the printed line:
+    <= 8 KB, the contract keys, `roofline`, `cpu_baseline`, `verified` and one compact row per side workload."""
+    b = _bench()
+    full = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r05", "bench_default_with_cpu_baseline.json")) if l.startswith("{")][0])
+    assert len(json.dumps(full)) > 20000
+    line = b.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) <= 8192 and json.loads(text) == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "verified", "build_id"):
+        assert k in line, k
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_GBps", "algorithmic_over_hbm_peak",
+              "frac_hbm_unique", "pmc_build_id", "pmc_matches_build"):
+        assert k in line["roofline"], k
+    assert set(line["config"]) >= {"workload", "name", "arithmetic"} and line["verified"]["ok"] is True
+    for k in ("north_star_10k", "flat_1024", "config4_256", "fast_config3", "fast_10k", "fast_config4", "config5_64k_one_gpu"):
+        row = line[k]
+        assert set(row) >= {"ms_per_step", "frame_frac", "bound", "frac", "verified_ok"} and len(json.dumps(row)) < 400, (k, row)
+    # a line that would still come out too long loses optional parts, never a contract key
+    fat = dict(full, **{k: dict(full["north_star_10k"], workload="x" * 3000) for k in b.SIDE_KEYS})
+    fat["config"] = dict(full["config"], workload="y" * 7000)
+    slim = b.compact_line(fat)
+    assert len(json.dumps(slim)) <= 8192 and "roofline" in slim and "cpu_baseline" in slim and "value" in slim
+
+
+DRIVER_COMMAND = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"]
+
+
 @pytest.mark.gpu
-def test_default_bench_line_has_every_contract_field():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--reps", "3", "--no-side"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+def test_the_drivers_exact_command_prints_one_parsable_line_in_time():
+    """EXACTLY what the driver runs at round end (`python3 bench.py --gpus 1 --steps 20 --warmup 5`): one `{`-line of at most
+    8 KB that parses, carries every contract field, `roofline`, `cpu_baseline`, an oracle-verified timed region and the side
+    rows -- within 40 s of wall time (round 5's took 64.7 s and 22.7 KB, and was not parsed)."""
+    import time
+    t0 = time.perf_counter()
+    r = subprocess.run(DRIVER_COMMAND, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    wall = time.perf_counter() - t0
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1 and len(r.stdout.strip().splitlines()) == 1
+    assert len(lines[0]) <= 8192, len(lines[0])
     d = json.loads(lines[0])
+    print(f"bench wall {wall:.1f} s, line {len(lines[0])} bytes, legs in bench_full.json")
+    assert wall <= 40.0, (wall, json.load(open(os.path.join(ROOT, "bench_full.json"))).get("legs_s"))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
+              "data", "config", "roofline", "cpu_baseline", "verified", "build_id"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["scaling"] == "weak" and d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_GBps"):
         assert k in d["roofline"], k
-    assert d["roofline"]["bound"] == d["roofline"]["limiter"]
     # the line says that what it timed is what the oracle computes (bench.Verifier): the launch sequence of the timed region
     ver = d["verified"]
-    assert ver["ok"] is True and ver["leaves"] >= 64 and ver["checkpoints"] >= 3 and ver["frames"] >= 3 * 10
+    assert ver["ok"] is True and ver["leaves"] >= 32 and ver["checkpoints"] >= 3 and ver["frames"] >= 3 * 20
     for path, v in _fracs(d):
         assert v is None or 0.0 <= v <= 1.0, (path, v)
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] in ("reference", "port")
     assert abs(d["value"] - d["steps"] * 74496000 / (d["ms_per_step"] * d["steps"] * 1e-3) / 1e6) / d["value"] < 0.01
-    assert "qt_adapter" in d["through_abi"] and "u8_dc_ms_per_frame" in d["through_abi"]
+    assert "u8_dc_pipelined_ms" in d["through_abi"]
+    # the side rows: measured ones are verified; the north-star ones must have fitted the budget
+    for k in ("north_star_10k", "fast_config3", "config4_256", "flat_10k"):
+        assert d[k].get("verified_ok") is True, (k, d[k])
+    for k in ("fast_10k", "fast_config4", "flat_1024", "config5_64k_one_gpu"):
+        assert d[k].get("verified_ok") is True or "skipped" in d[k], (k, d[k])
+    # everything else is beside the line
+    full = json.load(open(os.path.join(ROOT, "bench_full.json")))
+    assert full["value"] == d["value"] and "valu" in full["roofline"] and "legs_s" in full and "through_abi" in full

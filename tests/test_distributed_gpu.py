@@ -75,10 +75,16 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     env = dict(os.environ, SDRX_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "8", "--warmup", "2", "--reps", "2"]
+    import time
+    t0 = time.perf_counter()
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - t0
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    # the limits of the N = 1 line hold for the N = 8 one: <= 8 KB, and -- with eight ranks sharing ONE GPU and its host -- a
+    # wall time that leaves the driver's SCALE run (four such commands) its minutes
+    assert len(lines[0]) <= 8192 and wall <= 120.0, (len(lines[0]), wall)
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["steps"] == 8
     assert out["config"]["sub_vfos_per_gpu"] == 1024 and out["config"]["vfos_total"] == 8 * 1024 + 2
@@ -110,3 +116,20 @@ def test_bench_rccl_branch_with_one_rank():
     assert out["n_gpus"] == 1 and "RCCL broadcast (4 per collective)" in out["config"]["parallelism"]
     assert out["value"] > 0 and out["config"]["sub_vfos_per_gpu"] == 1024
     assert "overlapped broadcast unavailable" not in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_refuses_to_measure_without_peer_access():
+    """a rank whose device cannot reach rank 0's directly (hipDeviceCanAccessPeer = 0: the raw-frame broadcast
+    would be staged through host memory) ends the run with rc 4 and the diagnosis on stderr instead of a slow number
+    (SDRX_BENCH_FAKE_NO_PEER=1 makes the last rank report 0 on this one-GPU box)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SDRX_BENCH_SHARE_GPU="1", SDRX_BENCH_FAKE_NO_PEER="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--reps", "1"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout[-500:]
+    assert "refusing to measure" in r.stderr and "[1, 0]" in r.stderr and "rocm-smi --showtopo" in r.stderr, r.stderr[-2000:]
