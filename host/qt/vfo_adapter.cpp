@@ -69,6 +69,8 @@ struct Tree {
     std::vector<const vfo *> taps;      // the nodes the library was last told about (fftVFOSlot -> sdrx_add_tap) ...
     std::vector<sdrx_ctx *> tap_ctxs;   // ... and the contexts that hold them
     long dropped = 0;                   // frames lost to a runtime error of the device path (logged, never fatal)
+    int consecutive = 0;                // ... in a row
+    bool lost = false;                  // the device path does not come back by itself: the next process() builds a new context
     ~Tree();
     const char *error() const { return grp ? sdrx_group_last_error(grp) : sdrx_last_error(ctx); }
     // deliver the oldest submitted frame: payloads -> transmit buffers -> ZmqPublisher, in the reference's order.
@@ -78,14 +80,36 @@ struct Tree {
     void deliver_one()
     {
         cursor = 0;
-        if ((grp ? sdrx_group_wait(grp) : sdrx_wait(ctx)) != SDRX_OK)
-            drop("sdrx_wait");
-        --in_flight;
+        const int before = in_flight;
+        const int rc = grp ? sdrx_group_wait(grp) : sdrx_wait(ctx);
+        in_flight = before - 1;
+        if (rc == SDRX_OK) {
+            consecutive = 0;
+        } else {
+            drop("sdrx_wait", rc);
+            // The library's own count is the truth: a wait that failed before the library took the frame off its queue has NOT
+            // delivered it, and a count of ours that ran ahead of the library's would make every later submit fail with
+            // "2 frames in flight" while the `while (in_flight > ...) deliver_one()` loops never drain the library.
+            const int q = grp ? sdrx_group_in_flight(grp) : sdrx_in_flight(ctx);
+            if (q >= before)
+                lost = true; // nothing left the queue: waiting again would spin -- the tree is rebuilt instead
+            else if (q >= 0)
+                in_flight = q;
+        }
+        if (lost)
+            in_flight = 0;
     }
-    void drop(const char *what)
+    // A transient error costs a frame.  HIP errors are sticky, though: after one, every later call of the context fails too.  So a
+    // HIP error -- or four failures in a row of any kind -- gives the tree up: the next process() on its root commits the same
+    // vfo objects to a NEW context (filter state restarts from zero: a time gap, as after MainWindow's stop / start).
+    void drop(const char *what, int rc)
     {
         ++dropped;
-        qWarning("sdrx adapter: %s failed, frame dropped (%ld so far): %s", what, dropped, error());
+        ++consecutive;
+        if (rc == SDRX_EHIP || consecutive >= 4)
+            lost = true;
+        qWarning("sdrx adapter: %s failed (%d), frame dropped (%ld so far)%s: %s", what, rc, dropped,
+                 lost ? "; the device context is given up and rebuilt with the next frame" : "", error());
     }
 };
 
@@ -272,6 +296,15 @@ void vfo::compress() {}
 void vfo::process(const std::vector<cpx_typef> &samples)
 {
     NodeState &me = side()[this];
+    if (me.tree && me.tree->lost && me.id == 0) {
+        // the device path of this tree failed for good (Tree::drop): let go of the context and commit the tree anew, below
+        const std::vector<vfo *> nodes = me.tree->nodes;
+        for (vfo *v : nodes) {
+            NodeState &st = side()[v];
+            st.tree.reset(); // (the last one destroys the Tree and with it the context)
+            st.id = -1;
+        }
+    }
     if (!me.tree) {
         // first frame for this root: commit it and everything below it
         std::shared_ptr<Tree> T = std::make_shared<Tree>();
@@ -400,9 +433,10 @@ void vfo::process(const std::vector<cpx_typef> &samples)
         if (rc == SDRX_DIFFERENT)
             rc = T.grp ? sdrx_group_process(T.grp, iq, n) : sdrx_process(T.ctx, iq, n);
         if (rc != SDRX_OK) {
-            T.drop("sdrx_process");
+            T.drop("sdrx_process", rc);
             return;
         }
+        T.consecutive = 0;
     } else {
         // submit(f); deliver f-1 -- or everything, while a spectrum tap wants this very frame's streams
         int rc = from ? sdrx_submit_if_same(T.ctx, from, iq, n) : SDRX_DIFFERENT;
@@ -410,7 +444,7 @@ void vfo::process(const std::vector<cpx_typef> &samples)
         if (rc == SDRX_DIFFERENT)
             rc = T.grp ? sdrx_group_submit(T.grp, iq, n) : sdrx_submit(T.ctx, iq, n);
         if (rc != SDRX_OK) {
-            T.drop("sdrx_submit");
+            T.drop("sdrx_submit", rc);
             return;
         }
         ++T.in_flight;

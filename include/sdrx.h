@@ -128,8 +128,9 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
  *                 by construction, at worst the sequential time (sdrx_stats.dc_blocks / dc_retried_blocks /
  *                 dc_fallback_blocks).
  *   "dc_blocks_per_step" 1 | 2 | 4 | 8: how many 1024-sample blocks one step of that evaluation takes side by
- *                 side (= waves of the one workgroup per component).  Same results for every value.  0 = the sequential
- *                 recurrence for every sample (~2.0 ms per frame: two waves, each alone with its dependent chain): A/B switch. */
+ *                 side (= waves of the one workgroup per component).  Same results for every value; anything else is
+ *                 SDRX_EINVAL.  (The sequential recurrence for every sample -- ~2.0 ms per frame: two waves, each alone
+ *                 with its dependent chain -- is option "dc_speculative" = 0, not a value of this one.) */
 int sdrx_set_option(sdrx_ctx *ctx, const char *name, int value);
 /* All of vfo::init for every node: NCO tables (oscillator.cpp:4-32), low-pass designs
  * (firfilter.cpp:64-119), Hilbert taps (dsp.cpp:184-217), zeroed filter state, buffers.
@@ -309,6 +310,11 @@ typedef struct sdrx_stats {
     int64_t dc_retried_blocks;           /*   / taken again on their own because the step of several blocks they were part of */
                                          /*   did not verify as a whole (and then did: not counted as redone)                */
 } sdrx_stats;
+/* Everything but the three dc_* counters is host-side bookkeeping and costs nothing.  Once the context has run a frame with
+ * correct_dc the dc_* counters live on the device: the call then WAITS for whatever is queued on the context's stream and
+ * copies them back (a measurement call: a host that polls it between sdrx_submit and sdrx_wait serialises the frame it has
+ * just queued).  They count what has EXECUTED, so they can lag `frames` by the frames still inside the launch pipeline
+ * of sdrx_process_device (sdrx_sync / sdrx_fetch first for a consistent reading). */
 int sdrx_get_stats(sdrx_ctx *ctx, sdrx_stats *out);
 /* Per-kernel GPU time from HIP events recorded on the launch stream.  enable=1 brackets every
  * kernel launch with events (small overhead: use for profiling runs, not for throughput runs).

@@ -175,6 +175,7 @@ struct sdrx_ctx {
     float *d_dc_work = nullptr;    // exact DC-bias removal: products P[2][stride] and estimates A[2][stride] of one frame
     unsigned long long *d_dc_counters = nullptr; // k_dc_chain_spec: [0] blocks walked, [1] blocks redone with the sequential operations, [2] blocks taken again on their own
     int dc_waves = 8;                            // k_dc_chain_spec: blocks per step = waves per workgroup (SDRX_DC_WAVES: 1, 2, 4, 8)
+    int dc_rounds = 0;                           //   ... its limit of rounds per step (SDRX_DC_ROUNDS; 0 = kDcMaxIter)
     int dc_work_stride = 0;
     double *d_dc_tab = nullptr;    // fast DC scan: powers of the decay + per-chunk sums behind them
     unsigned long long dc_frames = 0; // frames the fast scan has run on (its state ping-pongs)
@@ -650,8 +651,23 @@ int sdrx_create(sdrx_ctx **out, int device)
     if (getenv("SDRX_LATE_COPY"))
         c->late_copy = atoi(getenv("SDRX_LATE_COPY")) != 0;
     c->upload_kernel = getenv("SDRX_UPLOAD_KERNEL") && atoi(getenv("SDRX_UPLOAD_KERNEL")) != 0;
-    if (getenv("SDRX_DC_WAVES"))
-        c->dc_waves = atoi(getenv("SDRX_DC_WAVES"));
+    // experiment switches of the exact DC-bias removal, read ONCE, here, and validated like the option they shadow
+    if (const char *e = getenv("SDRX_DC_WAVES")) {
+        const int v = atoi(e);
+        if (v != 1 && v != 2 && v != 4 && v != 8) {
+            sdrx_destroy(c);
+            return fail(nullptr, SDRX_EINVAL, "SDRX_DC_WAVES=%s: 1, 2, 4 or 8 (option dc_blocks_per_step)", e);
+        }
+        c->dc_waves = v;
+    }
+    if (const char *e = getenv("SDRX_DC_ROUNDS")) {
+        const int v = atoi(e);
+        if (v < 1 || v > 1000) {
+            sdrx_destroy(c);
+            return fail(nullptr, SDRX_EINVAL, "SDRX_DC_ROUNDS=%s: 1 .. 1000 rounds per step of k_dc_chain_spec", e);
+        }
+        c->dc_rounds = v;
+    }
     if (getenv("SDRX_DOWNLOAD_BLOCKS"))
         c->download_blocks = std::max(0, std::min(4096, atoi(getenv("SDRX_DOWNLOAD_BLOCKS"))));
     // odd frames' payloads leave on a copy stream of their own: the next copy's set-up then overlaps the
@@ -1691,7 +1707,7 @@ int enqueue_u8_device(sdrx_ctx *c, const void *dev_bytes, int n_complex, int cor
             auto chain = c->dc_waves >= 8 ? k_dc_chain_spec<8> : c->dc_waves >= 4 ? k_dc_chain_spec<4> : c->dc_waves >= 2 ? k_dc_chain_spec<2> : k_dc_chain_spec<1>;
             const int waves = c->dc_waves >= 8 ? 8 : c->dc_waves >= 4 ? 4 : c->dc_waves >= 2 ? 2 : 1;
             hipLaunchKernelGGL(chain, dim3(2), dim3(64 * waves), 0, c->stream, Pp, Ap, n_complex, c->dc_work_stride, c->d_dc_state, c->d_dc_counters,
-                               getenv("SDRX_DC_ROUNDS") ? atoi(getenv("SDRX_DC_ROUNDS")) : kDcMaxIter);
+                               c->dc_rounds > 0 ? c->dc_rounds : kDcMaxIter);
         } else {
             hipLaunchKernelGGL(k_dc_chain, dim3(2), dim3(64), 0, c->stream, Pp, Ap, n_complex, c->dc_work_stride, c->d_dc_state);
         }
@@ -1852,12 +1868,14 @@ int start_owed_copy(sdrx_ctx *c)
     const int p = (int)((c->frame_no - (unsigned long long)c->in_flight) & 1ull);
     if (!c->copy_owed[p])
         return SDRX_OK;
-    c->copy_owed[p] = false;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t cs = (p && c->copy_stream2) ? c->copy_stream2 : c->copy_stream;
     HIPCHK(c, hipEventSynchronize(c->ev_tail[p]));
     HIPCHK(c, hipMemcpyAsync(c->h_pay[p], c->d_pay[p], c->pay_bytes, hipMemcpyDeviceToHost, cs));
     HIPCHK(c, hipEventRecord(c->ev_copied[p], cs));
+    // only now: a wait retried after one of the calls above failed must find the copy still owed -- ev_copied[p] is still the
+    // event of frame f - 2, which completed long ago, and h_pay[p] still holds THAT frame's payloads
+    c->copy_owed[p] = false;
     return SDRX_OK;
 }
 // the oldest undelivered frame's payloads are in host memory afterwards (slot returned); no callbacks

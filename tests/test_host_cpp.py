@@ -73,7 +73,11 @@ def _check_dump(rows, topo):
         assert np.float32(r["gain"]) == np.float32(v.gain)
 
 
-@pytest.mark.parametrize("ini", [INI_25E_LIKE, INI_54W_LIKE])
+INI_25E_OFFSET = INI_25E_LIKE.replace("mix_offset=0", "mix_offset=-1750")   # mainwindow.cpp:65,151: added to every sub VFO's frequency
+INI_25E_OFFSET_FAR = INI_25E_LIKE.replace("mix_offset=0", "mix_offset=-700000")  # ... far enough to move VFO19 under the other main
+
+
+@pytest.mark.parametrize("ini", [INI_25E_LIKE, INI_54W_LIKE, INI_25E_OFFSET, INI_25E_OFFSET_FAR])
 def test_cpp_ini_front_door_matches_python_rules(ini, tmp_path):
     _check_dump(_dump(ini, tmp_path), tp.topology_from_ini(ini))
 

@@ -55,6 +55,26 @@ def test_ini_rules_25e_like():
     assert (c.parent, c.fs, c.decimate_count, c.mixer_freq, c.filter_bw, c.output_rate) == (1, 192000, 2, -41300.0, 10000, 48000)
 
 
+def test_ini_rules_with_a_mix_offset():
+    """mainwindow.cpp:65,151: `mix_offset` is added to every SUB VFO's frequency before anything is derived from it -- its mixer
+    (centre - main - frequency) and the choice of its main VFO -- and to no main VFO's (mainwindow.cpp:106)."""
+    base = tp.topology_from_ini(INI_25E_LIKE)
+    for off in (1500, -2500):
+        t = tp.topology_from_ini(INI_25E_LIKE.replace("mix_offset=0", f"mix_offset={off}"))
+        assert [(v.mixer_freq, v.decimate_count) for v in t.vfos[:2]] == [(v.mixer_freq, v.decimate_count) for v in base.vfos[:2]]
+        for v, b in zip(t.vfos[2:], base.vfos[2:]):
+            assert v.mixer_freq == b.mixer_freq - off
+            assert (v.parent, v.fs, v.decimate_count, v.filter_bw, v.gain, v.samples_per_buffer) == \
+                (b.parent, b.fs, b.decimate_count, b.filter_bw, b.gain, b.samples_per_buffer)
+    # an offset that carries a sub VFO out of its main's band and into the other main's: |main - (f + offset)| < out_rate picks
+    # the FIRST main that covers it (mainwindow.cpp:179-191).  VFO19 sits 41.3 kHz above main 2 (1 546 096 000, 192 k wide) and
+    # 1 021.3 kHz above main 1 (384 k wide): -700 000 Hz puts it 321.3 kHz above main 1 -> inside main 1's band
+    t = tp.topology_from_ini(INI_25E_LIKE.replace("mix_offset=0", "mix_offset=-700000"))
+    c = t.vfos[4]
+    assert c.topic == "VFO19" and c.parent == 0 and c.fs == 384000 and c.mixer_freq == float(1545116000 - (1546137300 - 700000))
+    assert c.decimate_count == 3 and c.output_rate == 48000  # 384 k -> 48 k below main 1
+
+
 def test_ini_rules_late_decimate_and_bufsplit():
     ini = """
 sample_rate=1920000

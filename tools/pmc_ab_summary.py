@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pmc_ab_summary.py <pmc_ab_dir> <out.json> -- condenses the counter passes of tools/r3d.sh (default build next to the
+"""tools/pmc_ab_summary.py <pmc_ab_dir> <out.json> -- condenses the counter passes of tools/archive/r3d.sh (default build next to the
 experiment builds -DSDRX_GLDS=1|2 and -DSDRX_NT=1, config 3 and 10 240 subs) into one table: per build, workload and
 kernel the pass duration, the calibrated VALU busy fraction, the wave-cycle split (SQ_WAIT_ANY / SQ_WAIT_INST_ANY /
 SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES), LDS and VMEM instruction counts, HBM-side bytes and the L2 hit rate."""
