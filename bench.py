@@ -46,8 +46,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-ARITH = {True: "exact (bit-identical to -O2 reference)",
-         False: "tolerance (<= 1e-5 of max|ref|, int16 within 1 LSB: NCO as rotations of its exact checkpoints, FMA mixer and filters)"}
+# option "exact" of include/sdrx.h (True == 1, False == 0: the same keys)
+ARITH = {1: "exact (bit-identical to -O2 reference)",
+         0: "tolerance (<= 1e-5 of max|ref|, int16 within 1 LSB: NCO as rotations of its exact checkpoints, FMA mixer and filters)",
+         2: "robust (<= 1e-5 of max|ref| whatever is out of band, int16 within 1 LSB: the table NCO exact, FMA mixer and filters)"}
 N_SIMD = 256 * 4       # 256 CUs x 4 SIMDs
 
 
@@ -218,12 +220,13 @@ class Verifier:
 def pmc_for(workload, exact):
     """profiles/current_pmc.json (tools/profile.sh + tools/pmc_summary.py): per-launch counter means of
     the committed PMC passes, if they were taken on this workload and arithmetic."""
-    for name in (f"pmc_{workload}.json" if exact else f"pmc_{workload}_tolerance.json", "current_pmc.json"):  # per-workload summaries next to the default one
+    suffix = {1: "", 0: "_tolerance", 2: "_robust"}[int(exact)]
+    for name in (f"pmc_{workload}{suffix}.json", "current_pmc.json"):  # per-workload summaries next to the default one
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
             continue
-        if pm.get("workload") == workload and pm.get("exact") == exact:
+        if pm.get("workload") == workload and int(pm.get("exact", -1)) == int(exact):
             return pm
     return None
 
@@ -242,9 +245,9 @@ def demanded_valu_per_launch(topo, exact=True):
     stage 0 8 x 11 + 16 halo moves, stage 1 4 x 11 + 16, an 11-instruction dot product per 64 outputs of every deeper stage
     (tools/inst_mix.py checks these counts against the compiled ISA); per 960 / 1008-sample chunk of a fused late
     decimation NCO + mix and 3 x Nd x 2 for the decimating low-pass.  TOLERANCE arithmetic: table entry and mixer 16 x (2 + 2),
-    a half-band output 3 pair sums + 1 product + 3 FMAs = 7, a low-pass tap one FMA.  Addressing, loop control, warm-up:
-    not demanded."""
-    nco_mix, hb, mac = (16 * 10, 11, 2) if exact else (16 * 4, 7, 1)
+    a half-band output 3 pair sums + 1 product + 3 FMAs = 7, a low-pass tap one FMA.  ROBUST arithmetic: the exact table replay
+    16 x 7 + the mixer 16 x 2, filters as in the tolerance arithmetic.  Addressing, loop control, warm-up: not demanded."""
+    nco_mix, hb, mac = (16 * 10, 11, 2) if int(exact) == 1 else (16 * 9, 7, 1) if int(exact) == 2 else (16 * 4, 7, 1)
     total = 0
     for v in topo.vfos:
         n, d = v.samples_per_buffer, v.decimate_count
@@ -457,12 +460,15 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="one k_mix_decimate launch per tree level instead of k_mix_levels (A/B switch)")
     ap.add_argument("--no-frame-pipeline", action="store_true", help="k_mix_levels, but every frame runs through all its levels at once (A/B switch)")
     ap.add_argument("--segments", type=int, default=0)
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="an option of sdrreceiver_amd.receiver.Receiver for every receiver of the run (A/B switches: fuse_demod=0, fuse_late=0, ...)")
     ap.add_argument("--batch", type=int, default=0, help="frames per broadcast at N > 1 (default 4)")
     ap.add_argument("--configs1", action="store_true",
                     help="also time BASELINE configs[1] (32 sub VFOs) and report it as a side reading (off by default: the "
                          "profiled default command must launch the kernels of ONE workload only)")
     args = ap.parse_args()
     n_reps = args.reps or (25 if args.full else 11)
+    user_options = {k: int(v) for k, v in (o.split("=", 1) for o in args.option)}
     budget = float("inf") if args.full else args.budget_s
     legs = {}  # wall seconds per leg of the run (bench_full.json): where the command's time goes
 
@@ -566,7 +572,7 @@ def main():
             if args.no_clock_warmup:
                 return
             t = tp.config3(1024)
-            self.rx = Receiver.from_topology(t, device=local, exact=not args.fast)
+            self.rx = Receiver.from_topology(t, device=local, exact=not args.fast, **user_options)
             self.rx.set_stream(stream.cuda_stream)
             self.frame = t.frame
             self.src = torch.from_numpy(synth.lcg_frame(t.frame, synth.Lcg(7))).to(dev)
@@ -597,13 +603,13 @@ def main():
         """One workload on this rank's shard: the Receiver, the raw-frame source and the broadcast."""
 
         def __init__(self, name, exact=None, options=None):
-            self.exact = (not args.fast) if exact is None else bool(exact)
+            self.exact = int(not args.fast) if exact is None else int(exact)   # option "exact": 1 | 0 tolerance | 2 robust
             self.full, self.descr = make_topology(name, world)
             self.topo = tp.shard(self.full, rank, world)
             self.frame = self.full.frame
             self.rx = Receiver.from_topology(self.topo, device=local, exact=self.exact, segments=args.segments,
                                              pipeline=args.pipeline, fuse=not args.no_fuse,
-                                             frame_pipeline=not args.no_frame_pipeline, **(options or {})) if self.topo.vfos else None
+                                             frame_pipeline=not args.no_frame_pipeline, **dict(user_options, **(options or {}))) if self.topo.vfos else None
             if self.rx:
                 self.rx.set_stream(stream.cuda_stream)
             self.st = self.rx.stats() if self.rx else {"vfo_samples_per_frame": 0, "algorithmic_bytes_per_frame": 0, "n_leaves": 0,
@@ -739,7 +745,7 @@ def main():
             o["kernels"] = {k: v["avg_ms"] for k, v in skern.items()}
             if sv:
                 try:
-                    o["verified"] = sv.finish(exact=j.exact)
+                    o["verified"] = sv.finish(exact=j.exact == 1)
                 except Exception as e:
                     o["verified"] = {"ok": None, "error": f"{type(e).__name__}: {e}"}
             j.close()
@@ -895,10 +901,10 @@ def main():
         # origin of the strong-scaling curve the N > 1 lines carry as `config5_strong`.  (key, workload, exact, seconds it needs)
         plan = [("north_star_10k", "10k", None, 4.0)]
         if not args.fast:
-            plan.append(("fast_config3", "config3", False, 2.5))
+            plan += [("fast_config3", "config3", 0, 2.5), ("robust_config3", "config3", 2, 2.5)]
         plan += [("config4_256", "config4", None, 2.5), ("flat_10k", "flat10k", None, 6.0)]
         if not args.fast:
-            plan += [("fast_10k", "10k", False, 4.0), ("fast_config4", "config4", False, 2.5)]
+            plan += [("fast_10k", "10k", 0, 4.0), ("fast_config4", "config4", 0, 2.5), ("robust_10k", "10k", 2, 4.0), ("robust_config4", "config4", 2, 2.5)]
         plan += [("flat_1024", "flat", None, 3.0), ("config5_64k_one_gpu", "64k", None, 9.0)]
         for key, name, ex, need in plan:
             side[key] = side_reading(key, name, exact=ex, need_s=need)
@@ -961,6 +967,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": descr, "name": full.name, "vfos_total": int(len(full.vfos)), "sub_vfos_per_gpu": int(st["n_leaves"]),
                        "frame_cf32": full.frame, "fs": full.fs, "arithmetic": ARITH[not args.fast],
+                       "options": user_options,
                        "parallelism": (f"vfo-shard x{world}, raw frames RCCL broadcast ({batch} per collective)" if use_dist else "single GPU"),
                        "launches": ("separate kernels, leaf tail of frame f beside the levels of frame f+1 (2 HIP streams)" if args.pipeline
                                     else "one kernel launch per tree level + leaf tail" if args.no_fuse

@@ -258,6 +258,19 @@ __device__ __forceinline__ v2f nco_mix_fast2(v2f base, v2f r0, v2f r1, v2f &x0, 
     x0 = y0, x1 = y1;
     return m1;
 }
+// The mixer alone in that form, two samples per statement:  x_k = m_k * x_k  (vfo.cpp:241) as one packed multiply and one packed
+// FMA each, alternating (the ROBUST arithmetic: table entries m_k from the exact recurrence, everything after them as FMAs).
+__device__ __forceinline__ void cmul_fast2(v2f m0, v2f m1, v2f &x0, v2f &x1)
+{
+    v2f y0, y1;
+    asm("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %3, %5 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(y0), "=&v"(y1)
+        : "v"(m0), "v"(m1), "v"(x0), "v"(x1));
+    x0 = y0, x1 = y1;
+}
 // the 16 entries behind checkpoint `c` and the mixer on the lane's 16 samples
 __device__ __forceinline__ void nco_mix_fast16(v2f c, const float2 *__restrict__ rk, v2f *x)
 {
@@ -1198,10 +1211,28 @@ __device__ __forceinline__ void load_run_tile(const float4 *__restrict__ src, v2
 // checkpoint `o` before it -- the exact recurrence, or in the tolerance arithmetic rotations of the checkpoint where the
 // chunk's `span` table entries from position i0 on are settled ones and do not wrap -- and multiply.  The very first sample
 // after start-up is multiplied by the LAST table entry (`last`: oscillator.cpp:30,39-50).
-template <bool EXACT>
+// Three arithmetics (option "exact"): EXACT -- the reference's operations in its order, every product and sum rounded.
+// !EXACT && ROT ("tolerance") -- table entries as rotations of the exact checkpoint, FMA mixer and filters: cheapest, but the
+// table's error (~1e-6 of |v|) multiplies the TOTAL input power, so a strong out-of-band carrier eats the 1e-5 bar.
+// !EXACT && !ROT ("robust") -- the table entries from the exact recurrence (error 0: bit-identical to the reference's table),
+// FMA mixer and filters: what remains is FMA-versus-two-roundings noise, ~6e-8 per operation, whatever is out of band.
+template <bool EXACT, bool ROT>
 __device__ __forceinline__ void nco_mix(v2f o, v2f rot, const float2 *__restrict__ rk, const float2 *__restrict__ last, bool first_ever, int i0,
                                         int span, int L, v2f *x)
 {
+    static_assert(!(EXACT && ROT), "the exact arithmetic replays the table");
+    if constexpr (!EXACT && !ROT) {
+#pragma unroll
+        for (int i = 0; i < kRun; i += 2) {
+            o = nco_step_pk(o, rot);
+            v2f m0 = o;
+            if (i == 0 && first_ever)
+                m0 = gldv2(last);
+            o = nco_step_pk(o, rot);
+            cmul_fast2(m0, o, x[i], x[i + 1]);
+        }
+        return;
+    }
     bool replay = true;
     if constexpr (!EXACT) // (wave-uniform)
         replay = i0 < kNcoSettle || i0 + span > L;
@@ -1278,13 +1309,251 @@ __device__ __forceinline__ void halo_stage1(v2f *car1, v2f *ext1, int lane)
         car1[0] = y[6];
 }
 
+// ------------------------------------------------------------------------------------ demod tail
+// `short = double` of the reference's x86-64 build (vfo.cpp:328,364): cvttsd2si truncates toward zero to
+// int32 and yields INT32_MIN ("integer indefinite") for anything outside int32 or NaN; the low 16 bits are
+// kept.  (The C standard calls the out-of-range case undefined; this is what the reference's binary does,
+// and what the oracle restates.)  v_cvt_i32_f64 truncates the same way but SATURATES, hence the select.
+__device__ __forceinline__ short to_short(double d)
+{
+    const int t = (d >= -2147483648.0 && d < 2147483648.0) ? (int)d : (int)0x80000000;
+    return (short)(unsigned short)(unsigned)t;
+}
+// The reference's two excursions into double on this path (vfo.cpp:317-328) are kept literally.  Both have
+// an fp32 form with identical results -- the exact difference of two floats rounded to 53 and then to 24
+// bits is the fp32 subtraction (double rounding is innocuous for + - * / when the wide format has
+// >= 2*24 + 2 significand bits), and `float * 2^15` is exact in either format with v_cvt_i32_f32
+// saturating like v_cvt_i32_f64 -- which -DSDRX_DEMOD_F32 selects: all 115 GPU parity tests pass with it,
+// and it is not faster (k_usb_demod 35.8-37.0 vs 35.7-36.6 us on config 3), so the literal form stays.
+__device__ __forceinline__ float usb_difference(float delayed_i, float hilbert)
+{
+#ifndef SDRX_DEMOD_F32
+    return (float)((double)delayed_i - (double)hilbert);
+#else
+    return delayed_i - hilbert;
+#endif
+}
+__device__ __forceinline__ float quantise(float scaled, short &out)
+{
+#ifndef SDRX_DEMOD_F32
+    const double pre = (double)scaled * 32768.0;
+    // |pre| < 2^31 <=> |scaled| < 2^16 (the product is exact): the range test of to_short() as ONE fp32 compare
+    out = fabsf(scaled) < 65536.0f ? (short)(unsigned short)(unsigned)(int)pre : (short)0;
+    return (float)pre; // exact: float * 2^15
+#else
+    const float pre = scaled * 32768.0f;
+    out = (short)(unsigned short)(unsigned)((pre >= -2147483648.0f && pre < 2147483648.0f) ? (int)pre : (int)0x80000000);
+    return pre;
+#endif
+}
+
+
+// ---- the USB demodulation INSIDE the leaf's wave (vfo::usb_demod, vfo.cpp:300-332) -----------------------------------------
+// A d = 2 leaf below a parent (the reference's 48 kS/s sub VFOs: 83 % of BASELINE config 3's demodulation work) turns every
+// 1024-sample chunk into 256 stream samples, four per lane -- and demodulates them on the spot: the leaf's cf32 stream never
+// reaches HBM (round 5: 63 MB written by the mix launch and 75 MB read back by k_usb_demod per frame of config 3), only
+// the int16 payload does.  Same arithmetic, same order as demod_block (one accumulator per output, taps ascending, every
+// product and sum rounded in the exact arithmetic):
+//   usb[m]  = I[m-62] - sum_{s<62} hnz[s] Q[m-123+2s]       (the 62 odd Hilbert taps; the even ones are exactly 0)
+//   usb'[m] = sum_{i<N} hu[i] usb[m-N+i]                    (FIR::FIRUpdateAndProcess: newest sample excluded, dsp.cpp:59-71)
+//   out[m]  = short(usb' * gain * 32768.0)
+// LDS of the wave (floats; all histories in FRONT of the chunk's new values, so a window is one contiguous run):
+//   QO [62 | 128]   odd-indexed Q of the stream (local index 2j+1 -> entry 62 + j): what the EVEN outputs read
+//   QE [3 + 62 | 128]  even-indexed Q, stored 3 floats up so that the b128 window reads of the odd outputs are aligned
+//   I  [2 + 62 | 256]  I, stored 2 floats up so that a lane's four new values are one aligned b128 write
+//   U  [Nh | 256 | 8]  usb: Nh = N rounded up to a multiple of 4 values of history, then the chunk's, then zeros the low-pass
+//                      reads under its zero padding taps
+//   H  [N + 15]        the low-pass taps with 3 zeros in front (K2Vfo::lpf_pad)
+// Output t = p + 8 q + 2 rr of lane (p = lane / 32, q = lane % 32) -- four outputs of equal parity share one contiguous run of
+// 65 plane entries (17 b128 reads for 248 MACs), the Hilbert taps are wave-uniform scalars (re-requested every chunk: 62 SGPRs
+// that are free again for the mix phase).  The low-pass then takes four CONSECUTIVE outputs per lane from U.
+// Between chunks the last 62 / 62 / 62 / Nh entries move to the front; between frames they live in K2Vfo::state (256 floats per
+// frame parity: QO | QE | I | U at 64-float strides), zero at start-up like every filter state of the reference (dsp.cpp:40-49).
+constexpr int kDmHist = 62;
+constexpr int kDmQO = 0, kDmQE = 192, kDmI = 388, kDmU = 708, kDmH = 1036, kDmFloats = 1116;
+constexpr int kDmMaxLpf = 64; // longest audio low-pass the wave applies itself (the reference's 10 kHz filter at 48 kS/s has 47 taps)
+static_assert(kDmQE - kDmQO >= kDmHist + 128 + 2 && kDmI - kDmQE >= 3 + kDmHist + 128 + 3 && kDmU - kDmI >= 2 + kDmHist + 256, "plane sizes");
+static_assert(kDmH - kDmU >= kDmMaxLpf + 256 + 8 && kDmFloats - kDmH >= kDmMaxLpf + 15, "usb / tap sizes");
+static_assert(kDmQE % 4 == 0 && kDmI % 4 == 0 && kDmU % 4 == 0 && kDmH % 4 == 0, "b128 alignment of the arrays");
+__host__ __device__ constexpr int demod_lds_bytes() { return kCarryBytes + 4 * kDmFloats; }
+
+struct DemodCtx { // wave-uniform (SGPRs): as little as possible lives across the mix phase -- the descriptor's fields are
+    const K2Vfo *Kp; //   re-read (scalar loads from the constant address space) where a chunk needs them
+    int par, nlpf, Nh;
+};
+__device__ __forceinline__ void demod_prologue(float *dm, const K2Vfo *Kp, int par, bool from_state, int lane, DemodCtx &C)
+{
+    C.Kp = Kp;
+    C.par = par;
+    C.nlpf = ldc(&Kp->nlpf);
+    C.Nh = (C.nlpf + 3) & ~3;
+    const float *st = ldc(&Kp->state[par]);
+    const float *lpf = ldc(&Kp->lpf_pad);
+    // all loads first, then the LDS writes
+    float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, t0 = 0.f, t1 = 0.f;
+    if (from_state && lane < kDmHist)
+        h0 = gld(st + lane), h1 = gld(st + 64 + lane), h2 = gld(st + 128 + lane);
+    if (from_state && lane < C.Nh)
+        h3 = gld(st + 192 + lane);
+    if (lane < C.nlpf + 15 && C.nlpf > 0)
+        t0 = gld(lpf + lane);
+    if (lane + 64 < C.nlpf + 15 && C.nlpf > 0)
+        t1 = gld(lpf + lane + 64);
+    const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int t = lane; t < kDmFloats / 4; t += 64)
+        reinterpret_cast<v4f *>(dm)[t] = z4;
+    wave_sync();
+    if (lane < kDmHist)
+        dm[kDmQO + lane] = h0, dm[kDmQE + 3 + lane] = h1, dm[kDmI + 2 + lane] = h2;
+    if (lane < C.Nh)
+        dm[kDmU + lane] = h3;
+    dm[kDmH + lane] = t0;
+    if (lane + 64 < kDmMaxLpf + 15)
+        dm[kDmH + 64 + lane] = t1;
+}
+// One chunk: z[0..3] = the lane's stream samples 4 lane .. 4 lane + 3 of the chunk (stream index g0 + ...), nv = how many of
+// the chunk's 256 are real (a multiple of 4), fo = first stream index this item emits, `last` = the chunk holds the frame's end.
+template <bool EXACT>
+__device__ __forceinline__ void demod_chunk(float *dm, const DemodCtx &C, const v2f *z, int lane, int nv, int g0, int fo, bool last)
+{
+    const K2Vfo *Kp = C.Kp;
+    asm volatile("" : "+s"(Kp)); // (what is read through it below is read in THIS chunk, not once in front of the chunk loop)
+    wave_sync(); // the previous chunk's reads and its hand-over are done
+    {
+        const v2f qo = {z[1].y, z[3].y};
+        *reinterpret_cast<v2f *>(dm + kDmQO + kDmHist + 2 * lane) = qo;
+        dm[kDmQE + 3 + kDmHist + 2 * lane] = z[0].y;
+        dm[kDmQE + 3 + kDmHist + 2 * lane + 1] = z[2].y;
+        const v4f iv = {z[0].x, z[1].x, z[2].x, z[3].x};
+        *reinterpret_cast<v4f *>(dm + kDmI + 2 + kDmHist + 4 * lane) = iv;
+    }
+    wave_sync();
+    // ---- Hilbert: four outputs of one parity per lane
+    {
+        const int p = lane >> 5, q = lane & 31;
+        const float *plane = p == 0 ? dm + kDmQO + 4 * q : dm + kDmQE + 4 + 4 * q;
+        // The taps sixteen at a time, each batch requested right in front of its pass (every chunk: hoisted out of the chunk
+        // loop, or all at once, they would hold 62 SGPRs -- the mix phase needs its own -- and spill into a VGPR that every
+        // body of the kernel then loses).  An accumulator still takes its taps in ascending order: pass k has s = 16 k .. 16 k + 15,
+        // i.e. plane entries rr + s in 16 k .. 16 k + 18: groups 4 k .. 4 k + 4 (20 b128 reads per chunk instead of 17).
+        const float *hnz_all = ldc(&Kp->hnz);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        static_for<4>([&](auto pass_ic) {
+            constexpr int pass = decltype(pass_ic)::value, s_lo = 16 * pass, s_hi = s_lo + 16 < kHilbertNz ? s_lo + 16 : kHilbertNz, g_lo = 4 * pass;
+            const float *hp = hnz_all + s_lo;
+            asm volatile("" : "+s"(hp));
+            float hnz[s_hi - s_lo];
+#pragma unroll
+            for (int s = 0; s < s_hi - s_lo; ++s)
+                hnz[s] = ldc(hp + s);
+#pragma unroll
+            for (int g = g_lo; g < g_lo + 5 && g < 17; ++g) {
+                const v4f v4 = *reinterpret_cast<const v4f *>(plane + 4 * g);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int s = 4 * g + e - rr;
+                        if (s >= s_lo && s < s_hi) {
+                            if (EXACT)
+                                acc[rr] = acc[rr] + hnz[s - s_lo] * v[e];
+                            else
+                                acc[rr] = fmaf(hnz[s - s_lo], v[e], acc[rr]);
+                        }
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0); // (the next batch of taps is not requested while this one is live)
+        });
+        const int t0 = p + 8 * q;
+        const float *iv = dm + kDmI + 2 + t0; // I[t - 62]
+        float *u = dm + kDmU + C.Nh + t0;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            u[2 * rr] = usb_difference(iv[2 * rr], acc[rr]);
+    }
+    wave_sync();
+    // ---- audio low-pass (newest sample excluded) on four consecutive outputs, int16
+    {
+        const int N = C.nlpf;
+        float u4[4];
+        if (N > 0) {
+            // output 4 lane + rr, tap i reads U[Nh + 4 lane + rr - N + i]; H[i + 3] = hu[i], zeros around
+            const float *w = dm + kDmU + (C.Nh - N) + 4 * lane;
+            const float *H = dm + kDmH;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const int groups = (N + 6) / 4;
+            for (int g = 0; g < groups; ++g) {
+                const v4f v4 = *reinterpret_cast<const v4f *>(w + 4 * g);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                const v4f ha = *reinterpret_cast<const v4f *>(H + 4 * g), hb4 = *reinterpret_cast<const v4f *>(H + 4 * g + 4);
+                const float h[8] = {ha.x, ha.y, ha.z, ha.w, hb4.x, hb4.y, hb4.z, hb4.w}; // h[k] = hu[4g + k - 3]
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        if (EXACT)
+                            acc[rr] = acc[rr] + h[e - rr + 3] * v[e];
+                        else
+                            acc[rr] = fmaf(h[e - rr + 3], v[e], acc[rr]);
+                    }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                u4[rr] = acc[rr];
+        } else {
+            const v4f v4 = *reinterpret_cast<const v4f *>(dm + kDmU + 4 * lane); // (Nh = 0)
+            u4[0] = v4.x, u4[1] = v4.y, u4[2] = v4.z, u4[3] = v4.w;
+        }
+        short o4[4];
+        float pq[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            pq[rr] = quantise(u4[rr] * ldc(&Kp->gain), o4[rr]);
+        const int g = g0 + 4 * lane;
+        if (4 * lane < nv && g >= fo) { // (nv and fo are multiples of 4: a lane's four outputs are emitted together or not at all)
+            const v4s o = {o4[0], o4[1], o4[2], o4[3]};
+            *(SDRX_AS1 v4s *)(ldc(&Kp->pay[C.par]) + g) = o;
+            float *prequant = ldc(&Kp->prequant);
+            if (prequant)
+                gst4(reinterpret_cast<float4 *>(prequant + g), make_float4(pq[0], pq[1], pq[2], pq[3]));
+        }
+    }
+    wave_sync();
+    // ---- the last 62 / 62 / 62 / Nh values: the next chunk's history, or -- at the frame's end -- the next frame's
+    if (last) {
+        const int h = nv >> 1;
+        float *state_save = ldc(&Kp->state[C.par ^ 1]);
+        if (lane < kDmHist) {
+            *(SDRX_AS1 float *)(state_save + lane) = dm[kDmQO + h + lane];
+            *(SDRX_AS1 float *)(state_save + 64 + lane) = dm[kDmQE + 3 + h + lane];
+            *(SDRX_AS1 float *)(state_save + 128 + lane) = dm[kDmI + 2 + nv + lane];
+        }
+        if (lane < C.Nh)
+            *(SDRX_AS1 float *)(state_save + 192 + lane) = dm[kDmU + nv + lane];
+    } else {
+        float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+        if (lane < kDmHist)
+            a = dm[kDmQO + 128 + lane], b = dm[kDmQE + 3 + 128 + lane], c = dm[kDmI + 2 + 256 + lane];
+        if (lane < C.Nh)
+            d = dm[kDmU + 256 + lane];
+        wave_sync();
+        if (lane < kDmHist)
+            dm[kDmQO + lane] = a, dm[kDmQE + 3 + lane] = b, dm[kDmI + 2 + lane] = c;
+        if (lane < C.Nh)
+            dm[kDmU + lane] = d;
+    }
+}
+
 // Fused NCO + mixer + half-band cascade.
 #ifndef SDRX_K1_MIN_WAVES
 #define SDRX_K1_MIN_WAVES 5 // waves per SIMD the register allocator must leave room for
 #endif
 // The body of one work item, run by ONE wave on LDS of its own (`smem`: k1_lds_bytes()); `level0`: the
 // item's VFO is fed by the raw frame (`raw`, `raw_mode`), otherwise by its parent's tile-layout stream.
-template <bool EXACT, int DEPTH>
+// DM: the leaf demodulates its stream in this very wave (demod_chunk; DEPTH == 2 only) -- decimate[2] itself is then written only
+// where it is wanted (K1Vfo::tap: the spectrum tap, option keep_streams).
+template <bool EXACT, int DEPTH, bool ROT, bool DM = false>
 __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K1Work W, unsigned long long frame_no,
                                          const void *__restrict__ raw, int raw_mode, bool level0_arg, unsigned char *smem, int lane)
 {
@@ -1326,6 +1595,11 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
             const int k = kCarry - lane; // carry position `lane` is x[-k]
             lds[stage_offset(s) + lane] = (from_state && k <= kHbHist) ? gldv2(hb_load + s * kHbHist + k - 1) : zero2;
         }
+    static_assert(!DM || DEPTH == 2, "the in-wave demodulation is laid out for 256 stream samples per chunk");
+    float *dm = reinterpret_cast<float *>(lds); // (DM: the demodulation's arrays live where a d = 2 leaf would park its held stores)
+    DemodCtx dmc;
+    if constexpr (DM)
+        demod_prologue(dm, ldc(&Dp->dm), par, from_state, lane, dmc);
     const int phase_frame = (int)((frame_no * (unsigned long long)D.n_in) % (unsigned long long)D.L);
 
     // The item walks 1024-sample chunks from sample s_begin (any multiple of 16: a chunk need not
@@ -1351,7 +1625,8 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
     HeldStores held;                      // the previous chunk's output stores (issued behind this chunk's loads)
     held.one = zero2;
     auto flush_held = [&]() {
-        if constexpr (!kShape) { // (the any-VFO body stores at once: an ordinary conditional store)
+        if constexpr (DM) { // (nothing is ever held: the payload leaves where it arises, 8 bytes per lane and chunk)
+        } else if constexpr (!kShape) { // (the any-VFO body stores at once: an ordinary conditional store)
             if (held.units == 1 && lane >= held.jmin && lane < held.nout)
                 gstv2_leaf(out + (size_t)(held.gbase + lane), held.one);
         } else if constexpr (DEPTH == 2) {
@@ -1405,7 +1680,7 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
         {
             int i0 = phase_frame + base;
             i0 -= i0 >= D.L ? D.L : 0;
-            nco_mix<EXACT>(o, rot, Dp->rk, D.cp + (D.L >> 4), frame_no == 0 && base == 0 && lane == 0, i0, kChunk, D.L, x);
+            nco_mix<EXACT, ROT>(o, rot, Dp->rk, D.cp + (D.L >> 4), frame_no == 0 && base == 0 && lane == 0, i0, kChunk, D.L, x);
         }
 
         if (dd == 0) {
@@ -1485,7 +1760,15 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
                         gstv4(reinterpret_cast<float4 *>(out + tile_pos(g + 2 * i)), cat2(z[2 * i], z[2 * i + 1]));
                 }
             }
-            if constexpr (kShape) { // its four outputs wait (in LDS) for the next chunk's loads to be on their way
+            if constexpr (DM) {
+                float2 *dm_tap = ldc(&Dp->tap[par]);
+                if (dm_tap && emit_l && active) { // decimate[2] is wanted too (fftVFOSlot, parity tests): natural order
+                    const int g = (base >> 2) + lane * 4;
+                    gstv4(reinterpret_cast<float4 *>(dm_tap + (size_t)g), cat2(z[0], z[1]));
+                    gstv4(reinterpret_cast<float4 *>(dm_tap + (size_t)(g + 2)), cat2(z[2], z[3]));
+                }
+                demod_chunk<EXACT>(dm, dmc, z, lane, valid >> 2, base >> 2, first_out >> 2, save);
+            } else if constexpr (kShape) { // its four outputs wait (in LDS) for the next chunk's loads to be on their way
                 v4f *park = reinterpret_cast<v4f *>(lds) + 2 * lane;
                 park[0] = cat2(z[0], z[1]);
                 park[1] = cat2(z[2], z[3]);
@@ -1555,7 +1838,7 @@ __device__ __forceinline__ void mix_item(const K1Vfo *__restrict__ vfos, const K
 // computes the three outputs k = base / L + 3 l + r from ONE pass over the 3 L - 1 + Nd samples that end in its row: window
 // sample u of lane l sits at l * kStride + const(u), the taps are wave-uniform scalars.  The last kCarryRows rows of a chunk
 // are the next chunk's history; the frame's last late_hist<L>() mixed samples are the next frame's (hb[]).
-template <bool EXACT, int LD>
+template <bool EXACT, int LD, bool ROT>
 __device__ __forceinline__ void late_item(const K1Vfo *__restrict__ vfos, const K1Work W, unsigned long long frame_no, unsigned char *smem,
                                           int lane)
 {
@@ -1619,7 +1902,7 @@ __device__ __forceinline__ void late_item(const K1Vfo *__restrict__ vfos, const 
             int i0 = phase_frame + base;
             i0 -= i0 >= D.L ? D.L : 0;
             // (kChunk, not kChunkLen: the lanes past the chunk replay entries nobody uses -- up to 64 x 16 of them must not wrap either)
-            nco_mix<EXACT>(o, rot, Dp->rk, D.cp + (D.L >> 4), frame_no == 0 && base == 0 && lane == 0, i0, kChunk, D.L, x);
+            nco_mix<EXACT, ROT>(o, rot, Dp->rk, D.cp + (D.L >> 4), frame_no == 0 && base == 0 && lane == 0, i0, kChunk, D.L, x);
         }
         if (tap && lane < G::kMixLanes && 16 * lane < valid && base + 16 * lane >= W.s_first_out) {
             // decimate[0] is wanted (the GUI's spectrum tap, parity tests)
@@ -1726,77 +2009,42 @@ __device__ __forceinline__ void late_item(const K1Vfo *__restrict__ vfos, const 
 }
 
 // which body a work item runs: the fused late decimation for the leaves marked so at finalize, the half-band cascade otherwise
-template <bool EXACT>
+template <bool EXACT, bool ROT>
 __device__ __forceinline__ void run_item(const K1Vfo *__restrict__ vfos, const K1Work W, unsigned long long frame_no,
                                          const void *__restrict__ raw, int raw_mode, bool level0, unsigned char *smem, int lane)
 {
     const int late = ldc(&vfos[W.vfo].late_L);
     if (late == 5)
-        late_item<EXACT, 5>(vfos, W, frame_no, smem, lane);
+        late_item<EXACT, 5, ROT>(vfos, W, frame_no, smem, lane);
     else if (late == 6)
-        late_item<EXACT, 6>(vfos, W, frame_no, smem, lane);
+        late_item<EXACT, 6, ROT>(vfos, W, frame_no, smem, lane);
     else {
         // a leaf fed from a tile-layout stream: the two shapes of the reference's sub VFOs have bodies of their own (0: any VFO)
         const bool leaf_on_tiles = !(level0 && raw_mode != kRawTiled) && !ldc(&vfos[W.vfo].out_tiled);
         const int d = ldc(&vfos[W.vfo].d);
         const int shape = leaf_on_tiles && d == kFixedDepth ? kFixedDepth : leaf_on_tiles && d == 2 ? 2 : 0;
-        if (shape == kFixedDepth)
-            mix_item<EXACT, kFixedDepth>(vfos, W, frame_no, raw, raw_mode, false, smem, lane);
+        if (shape == 2 && ldc(&vfos[W.vfo].dm) != nullptr) // (set at finalize for exactly such leaves: option fuse_demod)
+            mix_item<EXACT, 2, ROT, true>(vfos, W, frame_no, raw, raw_mode, false, smem, lane);
+        else if (shape == kFixedDepth)
+            mix_item<EXACT, kFixedDepth, ROT>(vfos, W, frame_no, raw, raw_mode, false, smem, lane);
         else if (shape == 2)
-            mix_item<EXACT, 2>(vfos, W, frame_no, raw, raw_mode, false, smem, lane);
+            mix_item<EXACT, 2, ROT>(vfos, W, frame_no, raw, raw_mode, false, smem, lane);
         else
-            mix_item<EXACT, -1>(vfos, W, frame_no, raw, raw_mode, level0, smem, lane);
+            mix_item<EXACT, -1, ROT>(vfos, W, frame_no, raw, raw_mode, level0, smem, lane);
     }
 }
 
 // One wave per workgroup, one workgroup per K1Work.  LEVEL only gives the root launch and the sub
 // launches distinct kernel names in profiles.
-template <bool EXACT, int LEVEL>
+template <bool EXACT, int LEVEL, bool ROT = !EXACT>
 __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_decimate(const K1Vfo *__restrict__ vfos, const K1Work *__restrict__ work,
                                                      unsigned long long frame_no, const void *__restrict__ raw, int raw_mode)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    run_item<EXACT>(vfos, work[blockIdx.x], frame_no, raw, raw_mode, LEVEL == 0, smem, (int)threadIdx.x);
+    run_item<EXACT, ROT>(vfos, work[blockIdx.x], frame_no, raw, raw_mode, LEVEL == 0, smem, (int)threadIdx.x);
 }
 
-// ------------------------------------------------------------------------------------ demod tail
-// `short = double` of the reference's x86-64 build (vfo.cpp:328,364): cvttsd2si truncates toward zero to
-// int32 and yields INT32_MIN ("integer indefinite") for anything outside int32 or NaN; the low 16 bits are
-// kept.  (The C standard calls the out-of-range case undefined; this is what the reference's binary does,
-// and what the oracle restates.)  v_cvt_i32_f64 truncates the same way but SATURATES, hence the select.
-__device__ __forceinline__ short to_short(double d)
-{
-    const int t = (d >= -2147483648.0 && d < 2147483648.0) ? (int)d : (int)0x80000000;
-    return (short)(unsigned short)(unsigned)t;
-}
-// The reference's two excursions into double on this path (vfo.cpp:317-328) are kept literally.  Both have
-// an fp32 form with identical results -- the exact difference of two floats rounded to 53 and then to 24
-// bits is the fp32 subtraction (double rounding is innocuous for + - * / when the wide format has
-// >= 2*24 + 2 significand bits), and `float * 2^15` is exact in either format with v_cvt_i32_f32
-// saturating like v_cvt_i32_f64 -- which -DSDRX_DEMOD_F32 selects: all 115 GPU parity tests pass with it,
-// and it is not faster (k_usb_demod 35.8-37.0 vs 35.7-36.6 us on config 3), so the literal form stays.
-__device__ __forceinline__ float usb_difference(float delayed_i, float hilbert)
-{
-#ifndef SDRX_DEMOD_F32
-    return (float)((double)delayed_i - (double)hilbert);
-#else
-    return delayed_i - hilbert;
-#endif
-}
-__device__ __forceinline__ float quantise(float scaled, short &out)
-{
-#ifndef SDRX_DEMOD_F32
-    const double pre = (double)scaled * 32768.0;
-    // |pre| < 2^31 <=> |scaled| < 2^16 (the product is exact): the range test of to_short() as ONE fp32 compare
-    out = fabsf(scaled) < 65536.0f ? (short)(unsigned short)(unsigned)(int)pre : (short)0;
-    return (float)pre; // exact: float * 2^15
-#else
-    const float pre = scaled * 32768.0f;
-    out = (short)(unsigned short)(unsigned)((pre >= -2147483648.0f && pre < 2147483648.0f) ? (int)pre : (int)0x80000000);
-    return pre;
-#endif
-}
-
+// ------------------------------------------------------------------------------------ demod tail (kernels of its own)
 // Late decimation by L in {5,6} (vfo.cpp:334-387 with FIR::FIRUpdateAndProcess/FIRUpdate,
 // dsp.cpp:59-71,150-154): z'[k] = sum_i hd[i] * x[L k - Nd + i]  -- the newest sample x[L k] is
 // NOT part of the sum ((N+1)-slot ring).  The phase counter restarts every frame and frames are
@@ -2193,7 +2441,7 @@ struct LevelArgs {
     int raw_mode;                               // ... and its form (kRaw*)
     int pad_;
 };
-template <bool EXACT>
+template <bool EXACT, bool ROT = !EXACT>
 __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_levels(const K1Vfo *__restrict__ k1, const K1Work *__restrict__ items,
                                                    const int *__restrict__ item_level, const int *__restrict__ list, LevelArgs A)
 {
@@ -2202,7 +2450,7 @@ __global__ __launch_bounds__(64, SDRX_K1_MIN_WAVES) void k_mix_levels(const K1Vf
     if (it < 0)
         return;
     const int lv = ldc(item_level + it);
-    run_item<EXACT>(k1, K1Work{ldc(&items[it].vfo), ldc(&items[it].s_begin), ldc(&items[it].s_first_out), ldc(&items[it].s_end)},
+    run_item<EXACT, ROT>(k1, K1Work{ldc(&items[it].vfo), ldc(&items[it].s_begin), ldc(&items[it].s_first_out), ldc(&items[it].s_end)},
                     A.frame_level[lv], A.raw, A.raw_mode, lv == 0, smem, (int)threadIdx.x);
 }
 

@@ -64,7 +64,10 @@ struct Node {
     uint32_t pay_len = 0;
     float rot_re = 0, rot_im = 0;
     int fused_late = 0;     // 5 | 6: the late decimation runs inside the mix wave (late_item); 0: not
-    bool has_stream = true; // decimate[d] of every frame is kept in HBM (false: a fused late decimation writes only z')
+    bool fused_demod = false; // the USB demodulation runs inside the mix wave (demod_chunk): the leaf writes its payload itself
+    size_t off_dstate[2] = {0, 0}; //   ... its demodulation history per frame parity (kDemodStateFloats floats)
+    int d2_index = -1;      // its K2Vfo in the demodulation descriptor array
+    bool has_stream = true; // decimate[d] of every frame is kept in HBM (false: a fused late decimation writes only z', a fused demodulation only the payload)
 };
 
 struct Launch1 { // one k_mix_decimate launch (a tree level)
@@ -112,7 +115,7 @@ struct sdrx_ctx {
     std::vector<Node> nodes;
     bool finalized = false;
     int opt_exact = 1, opt_prequant = 0, opt_segments = 0, opt_dc_blocked = 0, opt_pipeline = 0, opt_dc_speculative = 1;
-    int opt_fuse = 1, opt_frame_pipeline = 1, opt_fuse_late = 1, opt_keep_streams = 0;
+    int opt_fuse = 1, opt_frame_pipeline = 1, opt_fuse_late = 1, opt_keep_streams = 0, opt_fuse_demod = 1;
     // sdrx_set_tap / sdrx_add_tap: the fused late-decimation leaves that keep decimate[0] because they are taps (vfo::fftVFOSlot
     // sets emitFFT on EVERY VFO whose topic matches, vfo.cpp:492-509): node -> its buffers per frame parity and the first
     // frame that fills them.  The first such leaf uses the arena's buffer, further ones buffers of their own (hipMalloc).
@@ -324,9 +327,12 @@ void launch_block_kernel(sdrx_ctx *c, const LaunchB &L, hipStream_t ts, unsigned
 //   * half-band state, NCO tables and the parents' streams are touched by the levels only;
 //   * d_pay[p] is written by the tail of f and read by the copy of f; its next writer is the tail of
 //     f+2, which the host does not submit before frame f was delivered (SDRX_MAX_IN_FLIGHT = 2).
-template <bool EXACT>
-int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode, bool egress)
+// ARITH = option "exact": 1 the exact arithmetic, 0 the tolerance arithmetic (NCO as rotations), 2 the robust one (exact NCO,
+// FMA mixer and filters) -- kernels.hip, nco_mix.
+template <int ARITH>
+int enqueue_frame_as(sdrx_ctx *c, const void *raw, int raw_mode, bool egress)
 {
+    constexpr bool EXACT = ARITH == 1, ROT = ARITH == 0;
     const K1Vfo *k1 = reinterpret_cast<const K1Vfo *>(c->arena + c->off_k1vfo);
     const int p = (int)(c->frame_no & 1ull);
     const bool pipe = c->opt_pipeline != 0;
@@ -367,9 +373,9 @@ int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode, bool egress)
         Bracket b(c, c->stream, L.kind, L.alg_bytes);
         const K1Work *w = reinterpret_cast<const K1Work *>(c->arena + L.off_work);
         if (L.level == 0)
-            hipLaunchKernelGGL((k_mix_decimate<EXACT, 0>), dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1, w, c->frame_no, raw, raw_mode);
+            hipLaunchKernelGGL((k_mix_decimate<EXACT, 0, ROT>), dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1, w, c->frame_no, raw, raw_mode);
         else
-            hipLaunchKernelGGL((k_mix_decimate<EXACT, 1>), dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1, w, c->frame_no,
+            hipLaunchKernelGGL((k_mix_decimate<EXACT, 1, ROT>), dim3(L.n_work), dim3(64), L.lds_bytes, c->stream, k1, w, c->frame_no,
                                (const void *)nullptr, kRawTiled);
     }
     hipStream_t ts = pipe ? c->tail_stream : c->stream;
@@ -413,6 +419,13 @@ int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode, bool egress)
     c->frame_no++;
     c->pending_fetch = !egress;
     return SDRX_OK;
+}
+
+int enqueue_frame(sdrx_ctx *c, const void *raw, int raw_mode, bool egress)
+{
+    return c->opt_exact == 1 ? enqueue_frame_as<1>(c, raw, raw_mode, egress)
+           : c->opt_exact == 2 ? enqueue_frame_as<2>(c, raw, raw_mode, egress)
+                               : enqueue_frame_as<0>(c, raw, raw_mode, egress);
 }
 
 void launch_block_kernel(sdrx_ctx *c, const LaunchB &L, hipStream_t ts, unsigned long long frame, bool exact)
@@ -487,17 +500,19 @@ int pipeline_step(sdrx_ctx *c, bool have_new, const void *raw, int raw_mode)
         const K1Work *items = reinterpret_cast<const K1Work *>(c->arena + P.off_items);
         const int *item_level = reinterpret_cast<const int *>(c->arena + P.off_item_level);
         const int *list = reinterpret_cast<const int *>(c->arena + P.off_list) + first;
-        if (c->opt_exact)
-            hipLaunchKernelGGL(k_mix_levels<true>, dim3(last - first), dim3(64), P.lds_bytes, c->stream, k1, items, item_level, list, A);
+        if (c->opt_exact == 1)
+            hipLaunchKernelGGL((k_mix_levels<true, false>), dim3(last - first), dim3(64), P.lds_bytes, c->stream, k1, items, item_level, list, A);
+        else if (c->opt_exact == 2)
+            hipLaunchKernelGGL((k_mix_levels<false, false>), dim3(last - first), dim3(64), P.lds_bytes, c->stream, k1, items, item_level, list, A);
         else
-            hipLaunchKernelGGL(k_mix_levels<false>, dim3(last - first), dim3(64), P.lds_bytes, c->stream, k1, items, item_level, list, A);
+            hipLaunchKernelGGL((k_mix_levels<false, true>), dim3(last - first), dim3(64), P.lds_bytes, c->stream, k1, items, item_level, list, A);
     }
     for (InFlight &q : c->pipe)
         q.next++;
     if (c->pipe.front().next >= n_levels) { // the oldest frame has passed its last level: its leaf tail, now
         const unsigned long long f = c->pipe.front().f;
         for (const LaunchB &L : c->lb)
-            launch_block_kernel(c, L, c->stream, f, c->opt_exact != 0);
+            launch_block_kernel(c, L, c->stream, f, c->opt_exact == 1);
         c->pipe.erase(c->pipe.begin());
     }
     hipError_t e = hipGetLastError();
@@ -726,7 +741,7 @@ int sdrx_set_option(sdrx_ctx *c, const char *name, int value)
     if (c->finalized)
         return fail(c, SDRX_ESTATE, "sdrx_set_option after sdrx_finalize");
     if (!strcmp(name, "exact"))
-        c->opt_exact = value != 0;
+        c->opt_exact = value == 2 ? 2 : value != 0; // 1 exact (default) | 0 tolerance | 2 robust
     else if (!strcmp(name, "keep_prequant"))
         c->opt_prequant = value != 0;
     else if (!strcmp(name, "segments"))
@@ -750,6 +765,8 @@ int sdrx_set_option(sdrx_ctx *c, const char *name, int value)
         c->opt_fuse_late = value != 0;
     else if (!strcmp(name, "keep_streams"))
         c->opt_keep_streams = value != 0;
+    else if (!strcmp(name, "fuse_demod"))
+        c->opt_fuse_demod = value != 0;
     else
         return fail(c, SDRX_EINVAL, "unknown option '%s'", name);
     return SDRX_OK;
@@ -879,6 +896,16 @@ int fused_late_of(const sdrx_ctx *c, const Node &n)
     return 0;
 }
 
+// Does this leaf demodulate inside its mix wave (demod_chunk, kernels.hip)?  The reference's 48 kS/s sub VFO: two half-band
+// stages below a parent (a tile-layout input, 256 stream samples per 1024-sample chunk), no late decimation, an audio low-pass of
+// at most kDmMaxLpf taps (the 10 kHz filter at 48 kS/s has 47).  Everything else keeps k_usb_demod.
+bool fused_demod_of(const sdrx_ctx *c, const Node &n)
+{
+    return c->opt_fuse_demod && n.leaf && n.d.demod_usb && n.d.late_decimate == 0 && n.d.decimate_count == 2 && n.d.parent_id >= 0 &&
+           !n.long_lpf && (int)n.lpf.size() <= kDmMaxLpf && n.d.samples_per_buffer >= kChunk;
+}
+constexpr int kDemodStateFloats = 256; // K2Vfo::state: QO | QE | I | U at 64-float strides
+
 // ---- per-node derived quantities: everything vfo::init computes (vfo.cpp:60-176)
 int derive_nodes(sdrx_ctx *c)
 {
@@ -958,8 +985,10 @@ int derive_nodes(sdrx_ctx *c)
         max_level = std::max(max_level, n.level);
     }
     c->n_levels = max_level + 1;
-    for (Node &n : c->nodes)
+    for (Node &n : c->nodes) {
         n.fused_late = fused_late_of(c, n);
+        n.fused_demod = fused_demod_of(c, n);
+    }
     return SDRX_OK;
 }
 
@@ -991,7 +1020,10 @@ void plan_buffers(sdrx_ctx *c, Built &B)
                 n.Hx = Hdemod; // the stream itself feeds the demodulator
             }
         }
-        n.has_stream = !n.fused_late || c->opt_keep_streams;
+        n.has_stream = !(n.fused_late || n.fused_demod) || c->opt_keep_streams;
+        if (n.fused_demod)
+            for (int p = 0; p < 2; ++p)
+                n.off_dstate[p] = plan.take(sizeof(float) * kDemodStateFloats);
         if (n.has_stream)
             for (int p = 0; p < 2; ++p) // a stream that feeds children is kept in whole 1024-sample tiles
                 n.off_stream[p] = plan.take(sizeof(float2) * (n.leaf ? (size_t)(n.Hx + n.n_f) : align_up((size_t)n.n_f, kChunk) + kChunk)); // (+1 tile: a shifted walk's idle lanes read past the last one)
@@ -1066,7 +1098,10 @@ int build_mix_work(sdrx_ctx *c, Built &B)
         // the half-band cascade's dependency cone, or the decimating low-pass's length (a multiple of 16 L: a segment of a
         // fused late decimation starts on an output AND on a 16-sample run)
         const int chunk = n.fused_late == 5 ? LateGeom<5>::kChunkLen : n.fused_late == 6 ? LateGeom<6>::kChunkLen : kChunk;
-        const int warm = n.fused_late == 5 ? LateGeom<5>::kWarm : n.fused_late == 6 ? LateGeom<6>::kWarm : warmup_samples(n.d.decimate_count);
+        // (a leaf that demodulates in its wave: behind the half-band warm-up another 124 stream samples until the Hilbert window
+        // holds real samples and N more until the audio low-pass does -- usb'[m] reads usb[m - N .. m - 1] --, 4 input samples each)
+        const int warm_demod = n.fused_demod ? (int)align_up((size_t)(warmup_samples(n.d.decimate_count) + ((kHilbert - 1 + (int)n.lpf.size()) << n.d.decimate_count)), 16) : 0;
+        const int warm = n.fused_late == 5 ? LateGeom<5>::kWarm : n.fused_late == 6 ? LateGeom<6>::kWarm : n.fused_demod ? warm_demod : warmup_samples(n.d.decimate_count);
         const int nchunks = (n_in + chunk - 1) / chunk;
         const int wch = (warm + chunk - 1) / chunk; // chunks a segment spends before its first exact output
         // few VFOs in the level (the 2-3 mains): segments as short as the warm-up allows;
@@ -1144,8 +1179,10 @@ int build_mix_work(sdrx_ctx *c, Built &B)
                 continue;
             need_tr |= n.d.decimate_count == 0 && n.leaf && !n.fused_late;
             lds_late = std::max(lds_late, n.fused_late == 5 ? late_lds_bytes<5>() : n.fused_late == 6 ? late_lds_bytes<6>() : 0);
-            // SURVEY.md 8d share of this launch: cf32 consumed (+ cf32 handed to children)
-            L.alg_bytes += 8ll * n.d.samples_per_buffer + (n.leaf ? 0ll : 8ll * n.n_f);
+            lds_late = std::max(lds_late, n.fused_demod ? demod_lds_bytes() : 0);
+            // SURVEY.md 8d share of this launch: cf32 consumed (+ cf32 handed to children; + the int16 payload of a leaf that
+            // demodulates in its wave)
+            L.alg_bytes += 8ll * n.d.samples_per_buffer + (n.leaf ? (n.fused_demod ? (int64_t)n.pay_len : 0ll) : 8ll * n.n_f);
         }
         L.lds_bytes = std::max(k1_lds_bytes(B.level_maxd[(size_t)lv], need_tr), lds_late);
         L.off_work = B.plan.take(sizeof(K1Work) * B.works[(size_t)lv].size());
@@ -1196,11 +1233,14 @@ void build_tail_work(sdrx_ctx *c, Built &B)
                 const int nl = n.long_lpf ? 0 : (int)n.lpf.size();
                 n.demod_tile = (nl > 0 && !getenv("SDRX_DEMOD_FULL_TILE")) ? ((kDemodTile - (nl + (nl & 1))) & ~3) : kDemodTile;
             }
-            for (int b = 0; b < (n.n_out + n.demod_tile - 1) / n.demod_tile; ++b)
+            // (a leaf that demodulates in its mix wave has a descriptor -- the wave reads it -- but no blocks in this launch)
+            for (int b = 0; !n.fused_demod && b < (n.n_out + n.demod_tile - 1) / n.demod_tile; ++b)
                 B.w2.push_back({(int)B.d2.size(), b});
+            n.d2_index = (int)B.d2.size();
             B.n2.push_back(i);
             B.d2.push_back(K2Vfo{});
-            b2 += n.pay_len; // W_out of SURVEY.md 8d
+            if (!n.fused_demod)
+                b2 += n.pay_len; // W_out of SURVEY.md 8d
             if (n.long_lpf) {
                 for (int b = 0; b < (n.n_out + 255) / 256; ++b)
                     B.w4.push_back({(int)B.d4.size(), b});
@@ -1226,7 +1266,7 @@ void build_tail_work(sdrx_ctx *c, Built &B)
         // Blocks are independent and the launch is a few resident rounds deep, so its tail is set by
         // what is dispatched last: longest blocks first (a block with the audio low-pass does about
         // twice the work; the last block of a VFO-frame may be nearly empty).
-        auto cost = [&](const BlockWork &b) {
+        auto cost = [&](const BlockWork &b) -> long long {
             const Node &n = c->nodes[(size_t)B.n2[(size_t)b.vfo]];
             const int outs = std::min(n.demod_tile, n.n_out - b.blk * n.demod_tile);
             return (long long)outs * (kHilbertNz + (long long)(n.long_lpf ? 0 : n.lpf.size()));
@@ -1235,8 +1275,9 @@ void build_tail_work(sdrx_ctx *c, Built &B)
     }
     if (!B.d2.empty()) {
         B.o2 = plan.take(sizeof(K2Vfo) * B.d2.size());
-        B.ow2 = plan.take(sizeof(BlockWork) * B.w2.size());
-        c->lb.push_back({KIND_DEMOD, (int)B.w2.size(), B.o2, B.ow2, 0, b2});
+        B.ow2 = plan.take(sizeof(BlockWork) * std::max<size_t>(1, B.w2.size()));
+        if (!B.w2.empty()) // (every USB leaf may demodulate in its own mix wave: no k_usb_demod launch at all then)
+            c->lb.push_back({KIND_DEMOD, (int)B.w2.size(), B.o2, B.ow2, 0, b2});
     }
     if (!B.d4.empty()) {
         int lds4 = 0;
@@ -1333,6 +1374,9 @@ int allocate_and_upload(sdrx_ctx *c, Built &B)
             if (n.fused_late) { // the wave writes the decimated stream itself; decimate[0] only where it is kept
                 k.out[p] = reinterpret_cast<float2 *>(P(n.off_z[p])) + n.H;
                 k.tap[p] = n.has_stream ? reinterpret_cast<float2 *>(P(n.off_stream[p])) : nullptr;
+            } else if (n.fused_demod) { // the wave writes the int16 payload itself; decimate[d] only where it is kept
+                k.out[p] = nullptr;
+                k.tap[p] = n.has_stream ? reinterpret_cast<float2 *>(P(n.off_stream[p])) + n.Hx : nullptr;
             } else {
                 k.out[p] = reinterpret_cast<float2 *>(P(n.off_stream[p])) + n.Hx;
             }
@@ -1354,6 +1398,7 @@ int allocate_and_upload(sdrx_ctx *c, Built &B)
         k.out_tiled = n.leaf ? 0 : 1;
         k.late_L = n.fused_late;
         k.late_taps = n.fused_late ? reinterpret_cast<const float *>(P(n.off_dec)) : nullptr;
+        k.dm = n.fused_demod ? reinterpret_cast<const K2Vfo *>(P(B.o2)) + n.d2_index : nullptr;
         jobs[(size_t)i] = NcoInit{reinterpret_cast<float2 *>(P(n.off_cp)), n.rot_re, n.rot_im, n.d.fs, 0};
     }
     for (size_t q = 0; q < B.d2a.size(); ++q) {
@@ -1376,13 +1421,15 @@ int allocate_and_upload(sdrx_ctx *c, Built &B)
         K2Vfo &k = B.d2[q];
         const bool late = n.d.late_decimate > 0;
         for (int p = 0; p < 2; ++p) {
-            k.s[p] = reinterpret_cast<const float2 *>(P(late ? n.off_z[p] : n.off_stream[p]));
-            k.s_next[p] = reinterpret_cast<float2 *>(P(late ? n.off_z[p ^ 1] : n.off_stream[p ^ 1]));
+            k.s[p] = n.fused_demod ? nullptr : reinterpret_cast<const float2 *>(P(late ? n.off_z[p] : n.off_stream[p]));
+            k.s_next[p] = n.fused_demod ? nullptr : reinterpret_cast<float2 *>(P(late ? n.off_z[p ^ 1] : n.off_stream[p ^ 1]));
         }
         k.hnz = reinterpret_cast<const float *>(P(n.off_hnz));
         k.lpf_pad = (n.lpf.empty() || n.long_lpf) ? nullptr : reinterpret_cast<const float *>(P(n.off_lpf));
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < 2; ++p) {
             k.usb_out[p] = n.long_lpf ? reinterpret_cast<float *>(P(n.off_u[p])) + n.Hu : nullptr;
+            k.state[p] = n.fused_demod ? reinterpret_cast<float *>(P(n.off_dstate[p])) : nullptr;
+        }
         for (int p = 0; p < 2; ++p)
             k.pay[p] = reinterpret_cast<short *>(c->d_pay[p] + n.pay_off);
         k.prequant = (c->opt_prequant) ? reinterpret_cast<float *>(P(n.off_preq)) : nullptr;
@@ -1652,7 +1699,7 @@ int enqueue_f32(sdrx_ctx *c, const float *iq, int n_complex, bool egress)
     rc = stage_host_frame(c, iq, (size_t)n_complex * sizeof(float2), dst);
     if (rc)
         return rc;
-    rc = c->opt_exact ? enqueue_frame<true>(c, dst, kRawF32, egress) : enqueue_frame<false>(c, dst, kRawF32, egress);
+    rc = enqueue_frame(c, dst, kRawF32, egress);
     if (rc == SDRX_OK)
         c->last_raw = kRawF32;
     return rc;
@@ -1726,7 +1773,7 @@ int enqueue_u8_device(sdrx_ctx *c, const void *dev_bytes, int n_complex, int cor
         mode = kRawTiled;
     }
     c->long_frame = correct_dc && !c->opt_dc_blocked;
-    const int rc = c->opt_exact ? enqueue_frame<true>(c, dev_bytes, mode, egress) : enqueue_frame<false>(c, dev_bytes, mode, egress);
+    const int rc = enqueue_frame(c, dev_bytes, mode, egress);
     c->long_frame = false;
     if (rc == SDRX_OK)
         c->last_raw = mode;
@@ -1753,7 +1800,7 @@ int sdrx_process_device(sdrx_ctx *c, const void *dev_iq, int n_complex)
     if (rc)
         return rc;
     c->last_raw = -1;
-    return c->opt_exact ? enqueue_frame<true>(c, dev_iq, kRawF32, false) : enqueue_frame<false>(c, dev_iq, kRawF32, false);
+    return enqueue_frame(c, dev_iq, kRawF32, false);
 }
 
 int sdrx_submit_device(sdrx_ctx *c, const void *dev_iq, int n_complex)
@@ -1762,7 +1809,7 @@ int sdrx_submit_device(sdrx_ctx *c, const void *dev_iq, int n_complex)
     if (rc)
         return rc;
     c->last_raw = -1;
-    return c->opt_exact ? enqueue_frame<true>(c, dev_iq, kRawF32, true) : enqueue_frame<false>(c, dev_iq, kRawF32, true);
+    return enqueue_frame(c, dev_iq, kRawF32, true);
 }
 
 int sdrx_submit(sdrx_ctx *c, const float *iq, int n_complex)
@@ -1821,7 +1868,7 @@ static int submit_shared(sdrx_ctx *c, sdrx_ctx *src, const char *what, bool sync
     HIPCHK(c, hipStreamWaitEvent(c->stream, src->ev_staged[p], 0));
     c->last_raw = -1; // (not this context's buffer: sdrx_get_raw is served by `src`)
     const int src_raw = src->last_raw;
-    rc = c->opt_exact ? enqueue_frame<true>(c, frame, src_raw, true) : enqueue_frame<false>(c, frame, src_raw, true);
+    rc = enqueue_frame(c, frame, src_raw, true);
     if (rc)
         return rc;
     if (hipEventRecord(slot->ev, c->stream) == hipSuccess)
@@ -2046,9 +2093,9 @@ int sdrx_get_stream(sdrx_ctx *c, int id, float *out, int max_complex, int *n_ret
     const auto tap = c->taps.find(id);
     if (!n.has_stream && !(tap != c->taps.end() && c->frame_no > tap->second.since))
         return fail(c, SDRX_ENOSTREAM,
-                    "sdrx_get_stream: vfo %d decimates by %d inside the mix wave and keeps no decimate[0] -- select it with sdrx_set_tap / "
-                    "sdrx_add_tap before the frame (the reference's fftVFOSlot), or set option keep_streams=1 / fuse_late=0",
-                    id, n.fused_late);
+                    "sdrx_get_stream: vfo %d %s inside the mix wave and keeps no decimate[%d] -- select it with sdrx_set_tap / "
+                    "sdrx_add_tap before the frame (the reference's fftVFOSlot), or set option keep_streams=1 / %s=0",
+                    id, n.fused_late ? "decimates by 5 / 6" : "demodulates", n.d.decimate_count, n.fused_late ? "fuse_late" : "fuse_demod");
     if (out && cnt > 0) {
         if (!n.has_stream) {
             HIPCHK(c, hipMemcpy(out, tap->second.buf[par], sizeof(float2) * (size_t)cnt, hipMemcpyDeviceToHost));

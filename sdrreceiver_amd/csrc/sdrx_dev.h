@@ -21,6 +21,7 @@ constexpr int kRawTiled = 0;        // the context's tile-layout copy (an ingest
 constexpr int kRawF32 = 1;          // the caller's cf32 frame, natural order
 constexpr int kRawU8 = 2;           // the dongle's interleaved bytes, natural order
 
+struct K2Vfo;
 // ---- mix + half-band cascade (one per VFO) ---------------------------------------------------
 struct K1Vfo {
     const float2 *in[2];   // input stream in TILE LAYOUT (see kernels.hip) per frame parity
@@ -43,6 +44,9 @@ struct K1Vfo {
     // rotation by the angle of (rot_re, rot_im) at unit modulus, computed in double and stored as floats -- 1 .. 4 steps of
     // the table's recurrence as one rotation, once its amplitude has settled (entries >= kNcoSettle).
     float2 rk[4];
+    // A USB leaf that demodulates in the mix wave itself (demod_chunk, kernels.hip; option fuse_demod): its demodulation
+    // descriptor.  `out` is then unused -- decimate[d] of such a leaf goes to HBM only through `tap`.
+    const K2Vfo *dm;
 };
 static_assert(sizeof(K1Vfo) % 8 == 0, "K1Vfo array stride");
 constexpr int kNcoSettle = 512; // table entries below this still carry the start-up ringing of the amplitude stabiliser (oscillator.cpp:20-28): always replayed exactly
@@ -121,6 +125,8 @@ struct K2Vfo {
     int pad_;
     float *usb_out[2];      // a low-pass longer than kMaxFir: the unfiltered usb floats go here per frame parity
                             //   (behind that stream's history) and k_lpf_long does the rest; else null
+    float *state[2];        // a leaf that demodulates in its mix wave: its demodulation history per frame parity (256 floats:
+                            //   the last 62 odd / 62 even Q, 62 I and Nh usb values at 64-float strides); else null
 };
 static_assert(sizeof(K2Vfo) % 8 == 0, "K2Vfo array stride");
 

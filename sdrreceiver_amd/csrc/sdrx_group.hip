@@ -99,7 +99,7 @@ int group_enqueue(sdrx_group *g, const void *src, size_t bytes, int raw_mode, bo
             // members' DC estimates identical, so no state ever has to travel between devices
             rc = enqueue_u8_device(M.c, raw, g->root_frame, 1, egress); // (leaves last_raw = tile layout: sdrx_get_raw serves it)
         } else {
-            rc = M.c->opt_exact ? enqueue_frame<true>(M.c, raw, raw_mode, egress) : enqueue_frame<false>(M.c, raw, raw_mode, egress);
+            rc = enqueue_frame(M.c, raw, raw_mode, egress);
         }
         if (rc) {
             g->broken = true; // earlier members already run this frame

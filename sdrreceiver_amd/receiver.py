@@ -26,13 +26,21 @@ class SdrxError(RuntimeError):
         self.code = code
 
 
+def arithmetic(exact) -> int:
+    """Option "exact" of include/sdrx.h: True / 1 / "exact" -> 1 (bit-identical to the -O2 reference), False / 0 / "tolerance" -> 0
+    (NCO as rotations of its exact checkpoints, FMA mixer and filters), 2 / "robust" -> 2 (exact NCO, FMA mixer and filters)."""
+    if isinstance(exact, str):
+        return {"exact": 1, "tolerance": 0, "fast": 0, "robust": 2}[exact]
+    return 2 if (exact is not True and exact == 2) else int(bool(exact))
+
+
 class Receiver:
     """One libsdrx context: a VFO tree on one GPU."""
 
     def __init__(self, device: int = 0, exact: bool = True, keep_prequant: bool = False, segments: int = 0,
                  dc_blocked_scan: bool = False, pipeline: bool = False, fuse: bool = True, frame_pipeline: bool = True,
                  fuse_late: bool = True, keep_streams: bool = False, dc_speculative: bool = True,
-                 dc_blocks_per_step: int | None = None):
+                 dc_blocks_per_step: int | None = None, fuse_demod: bool = True):
         self.L = _lib.lib()
         h = C.c_void_p()
         rc = self.L.sdrx_create(C.byref(h), int(device))
@@ -43,7 +51,7 @@ class Receiver:
         self.published: list[tuple[bytes, int, bytes]] = []
         self._cb = _lib.PUBLISH_FN(self._on_publish)
         self._chk(self.L.sdrx_set_publish_callback(self.h, self._cb, None))
-        self._chk(self.L.sdrx_set_option(self.h, b"exact", int(bool(exact))))
+        self._chk(self.L.sdrx_set_option(self.h, b"exact", arithmetic(exact)))
         self._chk(self.L.sdrx_set_option(self.h, b"keep_prequant", int(bool(keep_prequant))))
         self._chk(self.L.sdrx_set_option(self.h, b"segments", int(segments)))
         self._chk(self.L.sdrx_set_option(self.h, b"dc_blocked_scan", int(bool(dc_blocked_scan))))
@@ -52,6 +60,7 @@ class Receiver:
         self._chk(self.L.sdrx_set_option(self.h, b"frame_pipeline", int(bool(frame_pipeline))))
         self._chk(self.L.sdrx_set_option(self.h, b"fuse_late", int(bool(fuse_late))))
         self._chk(self.L.sdrx_set_option(self.h, b"keep_streams", int(bool(keep_streams))))
+        self._chk(self.L.sdrx_set_option(self.h, b"fuse_demod", int(bool(fuse_demod))))
         self._chk(self.L.sdrx_set_option(self.h, b"dc_speculative", int(bool(dc_speculative))))
         if dc_blocks_per_step is not None:
             self._chk(self.L.sdrx_set_option(self.h, b"dc_blocks_per_step", int(dc_blocks_per_step)))
@@ -190,8 +199,8 @@ class Receiver:
         return rate.value
 
     def stream(self, vid: int, missing_ok: bool = False):
-        """decimate[decimateCount] of VFO `vid` after the last frame.  A leaf whose late decimation runs inside the
-        mix wave keeps it only while it is the tap (:meth:`set_tap`) or with ``keep_streams``: SdrxError otherwise,
+        """decimate[decimateCount] of VFO `vid` after the last frame.  A leaf whose late decimation or whose demodulation runs
+        inside the mix wave keeps it only while it is the tap (:meth:`set_tap`) or with ``keep_streams``: SdrxError otherwise,
         or None with `missing_ok`."""
         n = C.c_int()
         rc = self.L.sdrx_get_stream(self.h, vid, None, 0, C.byref(n))
@@ -285,7 +294,7 @@ class Group:
         self._cb = _lib.PUBLISH_FN(lambda user, topic, rate, buf, length: self.published.append(
             (C.string_at(topic, 5), int(rate), C.string_at(buf, length))))
         self._chk(self.L.sdrx_group_set_publish_callback(self.h, self._cb, None))
-        self._chk(self.L.sdrx_group_set_option(self.h, b"exact", int(bool(exact))))
+        self._chk(self.L.sdrx_group_set_option(self.h, b"exact", arithmetic(exact)))
         for k, v in options.items():
             self._chk(self.L.sdrx_group_set_option(self.h, k.encode(), int(v)))
 

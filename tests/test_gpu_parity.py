@@ -101,7 +101,14 @@ def test_designed_taps_bit_exact(Receiver):
 # How a /5 or /6 leaf with decimate_count 0 runs (options "fuse_late", "keep_streams"): the default -- the decimating
 # low-pass inside the mix wave, decimate[0] never written --, the same keeping decimate[0] of every frame, and the
 # two-kernel form of rounds 1-3.  Results must not differ by one bit.
-LATE_MODES = {"fused": dict(), "fused+streams": dict(keep_streams=True), "two kernels": dict(fuse_late=False)}
+# The same three forms for a leaf that DEMODULATES inside its mix wave (option "fuse_demod": d = 2 below a parent -- the
+# reference's 48 kS/s sub VFOs): payload straight from the wave, the same keeping decimate[2], and k_usb_demod reading the
+# stream back from HBM.
+LATE_MODES = {"fused": dict(), "fused+streams": dict(keep_streams=True), "two kernels": dict(fuse_late=False, fuse_demod=False)}
+
+
+def _has_fused_leaves(topo):
+    return any(v.demod_usb and v.parent >= 0 and (v.late_decimate or v.decimate_count == 2) for v in topo.vfos)
 
 
 @pytest.mark.parametrize("late", sorted(LATE_MODES))
@@ -111,8 +118,8 @@ def test_exact_mode_against_reference_fixtures(Receiver, fixture, late):
     payload and stream on every VFO and frame (crosses the NCO table wrap, > 1 s of signal)."""
     key, frames = GOLDEN_TREES[fixture]
     topo = golden_topology(key)
-    if late != "fused" and not any(v.late_decimate for v in topo.vfos):
-        pytest.skip("no late decimation in this tree")
+    if late != "fused" and not _has_fused_leaves(topo):
+        pytest.skip("no leaf of this tree is fused into its mix wave")
     g = golden(fixture)
     rx = Receiver.from_topology(topo, exact=True, **LATE_MODES[late])
     for f, iq in _frames(topo, frames):
@@ -129,8 +136,8 @@ def test_exact_mode_against_reference_fixtures(Receiver, fixture, late):
 @pytest.mark.parametrize("key,frames", [("config1", 5), ("profile_25e", 5), ("54w", 3), ("288k", 6), ("compress", 2)])
 def test_exact_mode_against_live_oracle(Receiver, key, frames, late):
     topo = golden_topology(key)
-    if late != "fused" and not any(v.late_decimate for v in topo.vfos):
-        pytest.skip("no late decimation in this tree")
+    if late != "fused" and not _has_fused_leaves(topo):
+        pytest.skip("no leaf of this tree is fused into its mix wave")
     rx = Receiver.from_topology(topo, exact=True, **LATE_MODES[late])
     nodes, roots = ob.build_tree("port", topo)
     for f, iq in _frames(topo, frames, seed=11, tones=[(-377000.0, 25.0), (251000.0, 11.0)]):
@@ -202,16 +209,82 @@ def test_capture_like_stream_through_the_shipped_profile(Receiver, arith, entry)
     rx.close()
 
 
+@pytest.mark.parametrize("arith", ["tolerance", "robust"])
 @pytest.mark.parametrize("key,frames", [("config1", 5), ("profile_25e", 3), ("54w", 3), ("288k", 3)])
-def test_fast_mode_within_tolerance(Receiver, key, frames):
+def test_fast_mode_within_tolerance(Receiver, key, frames, arith):
     topo = golden_topology(key)
-    rx = Receiver.from_topology(topo, exact=False, keep_prequant=True)
+    rx = Receiver.from_topology(topo, exact=arith, keep_prequant=True)
     nodes, roots = ob.build_tree("port", topo)
     for f, iq in _frames(topo, frames, seed=5, tones=[(-377000.0, 25.0)]):
         rx.process(iq)
         ob.process_roots(roots, iq)
         _check_tolerance(rx, nodes, topo, (key, f))
     rx.close()
+
+
+def _relative_errors(rx, nodes, topo):
+    """per VFO: max|gpu - ref| / max|ref| on the final complex stream and (USB leaves) on the pre-quantisation float, and the
+    largest int16 difference"""
+    out = {}
+    for i, v in enumerate(topo.vfos):
+        ref = nodes[i].stream()
+        got = rx.stream(i, missing_ok=True)
+        e_s = float(np.abs(got - ref).max() / max(float(np.abs(ref).max()), 1e-30)) if got is not None else 0.0
+        e_p, lsb = 0.0, 0
+        if not topo.children(i) and v.demod_usb:
+            pre_ref = nodes[i].usb_prequant()
+            e_p = float(np.abs(rx.prequant(i).astype(np.float64) - pre_ref).max() / max(float(np.abs(pre_ref).max()), 1e-30))
+            lsb = int(np.abs(rx.output(i).astype(np.int32) - nodes[i].usb().astype(np.int32)).max())
+        out[v.topic or f"main{i}"] = (e_s, e_p, lsb)
+    return out
+
+
+# (Hz from the raw centre, LSB): outside both main VFOs' bands / 2 kHz into VFO05's 12 kHz channel: the neighbours of VFO05
+# (VFO06 5 kHz away, VFO04 ...) get it as an interferer 40 dB over their own noise after the main VFO's decimation
+ADVERSARIAL_CARRIERS = {"carrier outside every band": (100000.0, 100.0), "carrier inside VFO05's passband": (-483866.0, 100.0)}
+# what the tolerance arithmetic was MEASURED at on these inputs (round 6, MI355X): its NCO error multiplies the total input
+# power, the bar is relative to the quiet channel's own output
+TOLERANCE_BREAKS_THE_BAR = {}
+
+
+@pytest.mark.parametrize("arith", ["tolerance", "robust", "exact"])
+@pytest.mark.parametrize("case", sorted(ADVERSARIAL_CARRIERS))
+def test_strong_carrier_over_quiet_channels(Receiver, case, arith):
+    """where does the 1e-5 bar of the tolerance arithmetic break?  The shipped sdr_25E tree under +-1 LSB of
+    noise and ONE carrier of 100 LSB -- 40 dB over everything a quiet VFO delivers -- outside every band, and inside another
+    VFO's passband.  The tolerance arithmetic's NCO is a rotation of its exact checkpoints (~1e-6 of |v| off the reference's
+    table): that error scales with the TOTAL input power while the bar is relative to each VFO's own output, so this input
+    is its worst case and the test documents the measured figure (an xfail carrying it where it exceeds 1e-5).  The ROBUST
+    arithmetic (exact NCO, FMA mixer and filters: option exact = 2) must stay below 1e-6, the exact one is bit-identical."""
+    topo = tp.profile_25e()
+    f_c, a_c = ADVERSARIAL_CARRIERS[case]
+    rx = Receiver.from_topology(topo, exact=arith, keep_prequant=True)
+    nodes, roots = ob.build_tree("port", topo)
+    rng = np.random.default_rng(606)
+    worst = {}
+    for f in range(5):  # (> 1 s: the sub VFOs' tables wrap)
+        iq = synth.tone_frame(topo.frame, topo.fs, [(f_c, a_c)], f * topo.frame) + rng.integers(-1, 2, 2 * topo.frame).astype(np.float32)
+        rx.process(iq)
+        ob.process_roots(roots, iq)
+        if arith == "exact":
+            _check_exact(rx, nodes, topo, (case, f))
+            continue
+        for k, (es, ep, lsb) in _relative_errors(rx, nodes, topo).items():
+            w = worst.get(k, (0.0, 0.0, 0))
+            worst[k] = (max(w[0], es), max(w[1], ep), max(w[2], lsb))
+    rx.close()
+    if arith == "exact":
+        return
+    top = sorted(worst.items(), key=lambda kv: -max(kv[1][0], kv[1][1]))
+    w_s, w_p, w_lsb = max(v[0] for v in worst.values()), max(v[1] for v in worst.values()), max(v[2] for v in worst.values())
+    report = (f"{arith}, {case}: worst stream {w_s:.2e}, worst pre-quantisation {w_p:.2e} of max|ref|, int16 within {w_lsb} LSB; "
+              + ", ".join(f"{k} {max(v[0], v[1]):.1e}" for k, v in top[:4]))
+    print(report)
+    assert max(w_s, w_p) < 1e-3 and w_lsb <= 1, report     # (sanity: an arithmetic error, not a different signal)
+    if arith == "robust":
+        assert max(w_s, w_p) <= 1e-6, report
+    elif max(w_s, w_p) > REL_TOL:
+        pytest.xfail("the tolerance arithmetic leaves the 1e-5 bar on this input (use exact = 2): " + report)
 
 
 @pytest.mark.parametrize("late", sorted(LATE_MODES))
