@@ -96,7 +96,7 @@ def cpu_baseline(workload):
     elif workload == "config2":
         topo, frames = tp.config2(), 20
     else:
-        topo, frames = tp.config3(128), 24   # ~230 M VFO-samples: ~4.5 s of the reference's one thread (+ ~2 s for the port's two readings)
+        topo, frames = tp.config3(128), 12   # ~115 M VFO-samples: ~2.2 s of the reference's one thread (+ the port's two readings; measured 6 s in all)
     sample = f"{topo.name}: {len(topo.vfos)} VFOs x {frames} frames of {topo.frame} cf32 (LCG input)"
     iq = synth.lcg_frame(topo.frame, synth.Lcg(1))
     out = {}
@@ -445,7 +445,7 @@ def main():
                     help="the tolerance arithmetic (option exact = 0: within 1e-5 of the reference, north_star's bar) instead of bit-exact")
     ap.add_argument("--full", action="store_true",
                     help="no time budget: every side workload, 25 repetitions, a larger oracle sample, the Qt drop-in legs")
-    ap.add_argument("--budget-s", type=float, default=30.0,
+    ap.add_argument("--budget-s", type=float, default=32.0,
                     help="wall-time budget of the default command: side workloads are started only while it lasts")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-abi", action="store_true", help="skip the through-the-ABI (host buffers, PCIe both ways) leg")

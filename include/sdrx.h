@@ -92,11 +92,13 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
  *            entries and the first sample ever are still replayed exactly), the mixer (vfo.cpp:241) a packed multiply +
  *            FMA, the half-band / FIR dot products FMAs: ~230 instead of ~390 vector instructions per 1024 samples.
  *            Its NCO error (~1e-6 of |v|) multiplies the TOTAL input power while the bar is relative to the VFO's own
- *            output: a strong out-of-band carrier over a quiet channel eats the margin
- *            (tests/test_gpu_parity.py::test_strong_carrier_over_quiet_channels documents where).
+ *            output: a strong out-of-band carrier over a quiet channel eats the margin -- 100 LSB of carrier over +-1 LSB of
+ *            noise: 6.4e-6 of max|stream|, 8.3e-6 on the pre-quantisation float
+ *            (tests/test_gpu_parity.py::test_strong_carrier_over_quiet_channels).
  *            2: the ROBUST arithmetic -- the table entries from the exact recurrence (bit-identical to the reference's
- *            table: no NCO error at all), the mixer and every filter as FMAs as with 0: what is left is FMA versus
- *            two roundings, ~6e-8 per operation, independent of what is out of band (~260 instructions per 1024 samples).
+ *            table: no NCO error at all), the mixer and every filter as FMAs as with 0 (~260 instructions per 1024 samples).
+ *            What is left is FMA versus two roundings -- the kind of difference the reference's own -Ofast build (as shipped)
+ *            has against its -O2 build, and on that adversarial input the same size: 4.3e-6 against their 4.0e-6.
  *   "keep_prequant" 1: also keep the pre-quantisation float `usb*gain*32768` per leaf
  *            (parity tests; sdrx_get_prequant).   default 0
  *   "segments" n: force n time-segments per VFO-frame in the decimation kernel (0 = auto).
@@ -119,11 +121,15 @@ int sdrx_add_vfo(sdrx_ctx *ctx, const sdrx_vfo_desc *desc, int *id_out);
  *            stream to HBM; decimate[0] of such a leaf is kept only while it is the tap (sdrx_set_tap) or with
  *            "keep_streams".  0 = the two-kernel form (the mixed stream goes to HBM and comes back): A/B switch.
  *            Results are bit-identical either way.
- *   "fuse_demod" 1 (default) | 0: a USB leaf with decimate_count 2 below a parent and an audio low-pass of at most 64 taps
- *            (the reference's 48 kS/s sub VFOs, vfo::usb_demod, vfo.cpp:300-332) demodulates inside its mix wave: 256 stream
- *            samples per 1024-sample chunk go from registers through the wave's LDS to int16 -- the leaf's cf32 stream
- *            never reaches HBM.  decimate[2] of such a leaf is kept only while it is the tap (sdrx_set_tap) or with
- *            "keep_streams".  0 = the stream goes to HBM and k_usb_demod reads it back: A/B switch.  Results are bit-identical.
+ *   "fuse_demod" 0 (default) | 1: with 1 a USB leaf with decimate_count 2 below a parent and an audio low-pass of at most 64
+ *            taps (the reference's 48 kS/s sub VFOs, vfo::usb_demod, vfo.cpp:300-332) demodulates inside its mix wave: 256
+ *            stream samples per 1024-sample chunk go from registers through the wave's LDS to int16 and the leaf's cf32
+ *            stream never reaches HBM (decimate[2] of such a leaf is kept only while it is the tap, sdrx_set_tap, or with
+ *            "keep_streams").  Results are bit-identical.  Measured on MI355X (round 6, profiles/README.md): it removes
+ *            138 MB of HBM traffic per frame of BASELINE config 3 and is SLOWER -- 0.123 vs 0.112 ms per frame exact, 0.102 vs
+ *            0.091 tolerance: the frame is bound by VALU issue, not by HBM, and the demodulation's plain fp32 MACs issue in
+ *            pairs only beside other waves doing the same (k_usb_demod: 80 % paired at 7 waves per SIMD) -- inside the mix
+ *            wave, five waves per SIMD most of which are in packed-fp32 phases, they do not.  Off by default; an A/B switch.
  *   "keep_streams" 0 (default) | 1: every such leaf also keeps decimate[d] of every frame (parity tests that
  *            compare every stream of the tree).
  *   "dc_blocked_scan" 0|1 (default 0): how sdrx_process_u8 removes the DC bias.  0 = the

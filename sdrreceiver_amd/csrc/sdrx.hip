@@ -115,7 +115,7 @@ struct sdrx_ctx {
     std::vector<Node> nodes;
     bool finalized = false;
     int opt_exact = 1, opt_prequant = 0, opt_segments = 0, opt_dc_blocked = 0, opt_pipeline = 0, opt_dc_speculative = 1;
-    int opt_fuse = 1, opt_frame_pipeline = 1, opt_fuse_late = 1, opt_keep_streams = 0, opt_fuse_demod = 1;
+    int opt_fuse = 1, opt_frame_pipeline = 1, opt_fuse_late = 1, opt_keep_streams = 0, opt_fuse_demod = 0;
     // sdrx_set_tap / sdrx_add_tap: the fused late-decimation leaves that keep decimate[0] because they are taps (vfo::fftVFOSlot
     // sets emitFFT on EVERY VFO whose topic matches, vfo.cpp:492-509): node -> its buffers per frame parity and the first
     // frame that fills them.  The first such leaf uses the arena's buffer, further ones buffers of their own (hipMalloc).

@@ -40,7 +40,7 @@ class Receiver:
     def __init__(self, device: int = 0, exact: bool = True, keep_prequant: bool = False, segments: int = 0,
                  dc_blocked_scan: bool = False, pipeline: bool = False, fuse: bool = True, frame_pipeline: bool = True,
                  fuse_late: bool = True, keep_streams: bool = False, dc_speculative: bool = True,
-                 dc_blocks_per_step: int | None = None, fuse_demod: bool = True):
+                 dc_blocks_per_step: int | None = None, fuse_demod: bool = False):
         self.L = _lib.lib()
         h = C.c_void_p()
         rc = self.L.sdrx_create(C.byref(h), int(device))

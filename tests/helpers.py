@@ -176,3 +176,23 @@ def random_topology(rng):
         else:
             leaf(-1, fs_root, n_root, 0)
     return t
+
+
+# ---- the adversarial input of VERDICT r5 item 3: a quiet band under one strong carrier -------------------------------------------
+# (Hz from the raw centre, LSB): outside both main VFOs' bands / 2 kHz into VFO05's 12 kHz channel -- its neighbours under main
+# VFO 1 get it as an interferer 40 dB over their own noise after the main VFO's decimation
+ADVERSARIAL_CARRIERS = {"carrier outside every band": (100000.0, 100.0), "carrier inside VFO05's passband": (-483866.0, 100.0)}
+# What the reference's OWN two builds (-O2, the canonical oracle, and -Ofast, as shipped: SDRReceiver.pro:74-75) differ by on these
+# inputs, max|a - b| / max|a| over every final complex stream of the sdr_25E tree, 5 frames (measured by
+# tests/test_oracle_vs_reference.py::test_reference_builds_under_a_strong_carrier, which holds the figures to +-15 %): rounding
+# noise of the fp32 mixer scales with the TOTAL input, the bar with the quiet channel's own output.
+REFERENCE_BUILDS_DIFFER = {"carrier outside every band": 2.14e-6, "carrier inside VFO05's passband": 4.01e-6}
+
+
+def adversarial_frames(topo, case, n_frames=5, seed=606):
+    """sdr_25E-shaped input: +-1 LSB of noise and ONE carrier of 100 LSB, phase-continuous over the frames"""
+    from sdrreceiver_amd import synth
+    f_c, a_c = ADVERSARIAL_CARRIERS[case]
+    rng = np.random.default_rng(seed)
+    for f in range(n_frames):
+        yield f, synth.tone_frame(topo.frame, topo.fs, [(f_c, a_c)], f * topo.frame) + rng.integers(-1, 2, 2 * topo.frame).astype(np.float32)

@@ -242,8 +242,6 @@ def test_every_sub_vfo_in_the_tolerance_arithmetic(workload, arith):
     ws, wp, frac = _every_sub_vfo_within_tolerance(topo, 8, arith)
     print(f"{workload}, {arith}: worst stream error {ws:.3g}, worst pre-quantisation error {wp:.3g} (of max|ref|); {frac:.3%} of the int16 samples differ by 1 LSB")
     assert ws < REL_TOL and wp < REL_TOL
-    if arith == "robust":  # (exact NCO, FMA mixer and filters: what is left is FMA-versus-two-roundings noise)
-        assert ws < 2e-6 and wp < 2e-6
 
 
 def test_all_10240_vfos_of_the_north_star_workload_bit_exact():
