@@ -443,6 +443,8 @@ def main():
     ap.add_argument("--workload", default=None)
     ap.add_argument("--fast", action="store_true",
                     help="the tolerance arithmetic (option exact = 0: within 1e-5 of the reference, north_star's bar) instead of bit-exact")
+    ap.add_argument("--arith", type=int, default=None, choices=[0, 1, 2],
+                    help="option \"exact\" of the library: 1 exact (default), 0 tolerance (= --fast), 2 robust (exact NCO, FMA mixer and filters)")
     ap.add_argument("--full", action="store_true",
                     help="no time budget: every side workload, 25 repetitions, a larger oracle sample, the Qt drop-in legs")
     ap.add_argument("--budget-s", type=float, default=32.0,
@@ -467,6 +469,8 @@ def main():
                     help="also time BASELINE configs[1] (32 sub VFOs) and report it as a side reading (off by default: the "
                          "profiled default command must launch the kernels of ONE workload only)")
     args = ap.parse_args()
+    arith = args.arith if args.arith is not None else (0 if args.fast else 1)  # option "exact" of the line's own workload
+    args.fast = arith != 1                                                      # (the side readings in the other arithmetics ride along with the exact line only)
     n_reps = args.reps or (25 if args.full else 11)
     user_options = {k: int(v) for k, v in (o.split("=", 1) for o in args.option)}
     budget = float("inf") if args.full else args.budget_s
@@ -572,7 +576,7 @@ def main():
             if args.no_clock_warmup:
                 return
             t = tp.config3(1024)
-            self.rx = Receiver.from_topology(t, device=local, exact=not args.fast, **user_options)
+            self.rx = Receiver.from_topology(t, device=local, exact=arith, **user_options)
             self.rx.set_stream(stream.cuda_stream)
             self.frame = t.frame
             self.src = torch.from_numpy(synth.lcg_frame(t.frame, synth.Lcg(7))).to(dev)
@@ -603,7 +607,7 @@ def main():
         """One workload on this rank's shard: the Receiver, the raw-frame source and the broadcast."""
 
         def __init__(self, name, exact=None, options=None):
-            self.exact = int(not args.fast) if exact is None else int(exact)   # option "exact": 1 | 0 tolerance | 2 robust
+            self.exact = arith if exact is None else int(exact)   # option "exact": 1 | 0 tolerance | 2 robust
             self.full, self.descr = make_topology(name, world)
             self.topo = tp.shard(self.full, rank, world)
             self.frame = self.full.frame
@@ -772,7 +776,7 @@ def main():
         with leg("main_verify"):
             ver.checkpoint(with_streams=True)
             try:  # (the oracle runs here, on the host, before the legs below put other frames through this receiver)
-                verified = ver.finish(exact=not args.fast)
+                verified = ver.finish(exact=arith == 1)
             except Exception as e:
                 verified = {"ok": None, "error": f"{type(e).__name__}: {e}"}
     if use_dist:  # every rank checks its own shard; the line reports the worst
@@ -966,7 +970,7 @@ def main():
             "scaling": "strong" if workload == "config5" else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": descr, "name": full.name, "vfos_total": int(len(full.vfos)), "sub_vfos_per_gpu": int(st["n_leaves"]),
-                       "frame_cf32": full.frame, "fs": full.fs, "arithmetic": ARITH[not args.fast],
+                       "frame_cf32": full.frame, "fs": full.fs, "arithmetic": ARITH[arith],
                        "options": user_options,
                        "parallelism": (f"vfo-shard x{world}, raw frames RCCL broadcast ({batch} per collective)" if use_dist else "single GPU"),
                        "launches": ("separate kernels, leaf tail of frame f beside the levels of frame f+1 (2 HIP streams)" if args.pipeline
@@ -986,9 +990,9 @@ def main():
         if verified is not None:
             out["verified"] = verified
         if dom:
-            pm = pmc_for(workload, not args.fast)
+            pm = pmc_for(workload, arith)
             out["roofline"] = roofline_object(dom, kt[dom], kt_steps, frame_kernel_ms, alg_bytes, world, pm, st["mix_chunks_per_frame"],
-                                              demanded_valu_per_launch(topo, not args.fast) if world == 1 else None)
+                                              demanded_valu_per_launch(topo, arith) if world == 1 else None)
         out["kernels"] = kernels
         if abi:
             out["through_abi"] = abi
@@ -1008,7 +1012,7 @@ def main():
             # plumbing case on this hardware (three ~10 us launches per frame)
             try:
                 t2 = tp.config2()
-                rx2 = Receiver.from_topology(t2, device=local, exact=not args.fast)
+                rx2 = Receiver.from_topology(t2, device=local, exact=arith)
                 rx2.set_stream(stream.cuda_stream)
                 st2 = rx2.stats()
                 for _ in range(args.warmup):

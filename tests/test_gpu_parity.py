@@ -332,7 +332,7 @@ def test_demodulation_inside_the_mix_wave(Receiver, frame_root, segments, arith)
     lens = []
     rx = Receiver.from_topology(topo, exact=arith, fuse_demod=True, keep_prequant=True, segments=segments)
     other = Receiver.from_topology(topo, exact=arith, fuse_demod=False, keep_prequant=True, segments=segments)
-    kept = Receiver.from_topology(topo, exact=arith, fuse_demod=True, keep_streams=True, segments=max(0, segments - 1))
+    kept = Receiver.from_topology(topo, exact=arith, fuse_demod=True, keep_streams=True, keep_prequant=True, segments=max(0, segments - 1))
     for i in range(1, 6):
         lens.append(len(rx.taps(i, "fir_usb")) if topo.vfos[i].filter_bw else 0)
     assert lens[0] == 0 and lens[1] % 4 != lens[2] % 4 and max(lens[:4]) <= 64 < lens[4], lens

@@ -69,6 +69,11 @@ INST_MIX_D5_TOLERANCE = {
 }
 
 
+# the robust arithmetic (option exact = 2): the table entries from the exact recurrence (7 packed instructions per step), the mixer
+# and the filters as in the tolerance arithmetic
+INST_MIX_D5_ROBUST = dict(INST_MIX_D5_TOLERANCE, nco_rotations=16 * 7)
+
+
 def key_of(name):
     for k, v in KERNEL_KEYS.items():
         if k in name:
@@ -142,7 +147,7 @@ def main():
         return calib(sys.argv[2], sys.argv[3])
     d, out = sys.argv[1], sys.argv[2]
     workload = sys.argv[3] if len(sys.argv) > 3 else "config3"
-    exact = (sys.argv[4] != "0") if len(sys.argv) > 4 else True
+    exact = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # option "exact": 1 | 0 tolerance | 2 robust
     passes = [read_pass(f, key_of) for f in sorted(glob.glob(os.path.join(d, "pmc*_counter_collection.csv")))]
     sha = "unknown"
     try:
@@ -169,8 +174,8 @@ def main():
             if k:
                 avg_us[k] = float(r["AverageNs"]) / 1e3
     res = {"source": os.path.relpath(d), "git_sha": sha, "build_id": build_id, "workload": workload, "exact": exact, "kernels": {},
-           "inst_mix": {"k_mix_decimate, d=5 sub VFO, per 1024-sample chunk (source count, packed = 1)": INST_MIX_D5 if exact else INST_MIX_D5_TOLERANCE,
-                        "sum": sum((INST_MIX_D5 if exact else INST_MIX_D5_TOLERANCE).values()),
+           "inst_mix": {"k_mix_decimate, d=5 sub VFO, per 1024-sample chunk (source count, packed = 1)": {1: INST_MIX_D5, 0: INST_MIX_D5_TOLERANCE, 2: INST_MIX_D5_ROBUST}[exact],
+                        "sum": sum({1: INST_MIX_D5, 0: INST_MIX_D5_TOLERANCE, 2: INST_MIX_D5_ROBUST}[exact].values()),
                         "isa_check": "tools/inst_mix.py: the static v_pk_mul/add/fma_f32 and DPP counts of kernels.s == the source count of the bodies compiled into the kernel (d = 5 leaf: 146/87.5/32/32 executed per chunk)"},
            "note": "per-launch medians; hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE correction); every derived "
                    "figure takes numerator, cycles and duration from ONE pass (tools/pmc_summary.py)"}

@@ -1,0 +1,5 @@
+#!/bin/bash
+O=gpurun_out/r6d; mkdir -p $O
+cd "$GRAFT_REPO_ROOT"
+S=$(date +%s); python3 -m pytest tests/test_gpu_parity.py -m gpu -q -x --durations=15 -k "not exact_mode_against and not fast_mode_within and not strong_carrier" > $O/pytest.log 2>&1; rc=$?; E=$(date +%s)
+echo "pytest rc $rc in $((E-S)) s"; tail -40 $O/pytest.log
