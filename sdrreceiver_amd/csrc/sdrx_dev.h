@@ -57,12 +57,15 @@ constexpr int kNcoSettle = 512; // table entries below this still carry the star
 // of kChunkLen samples (a multiple of 16 L, so that a chunk starts on an output and a lane's 16-sample run on a run of the
 // tile layout) = kMixLanes lanes of 16 consecutive samples for the NCO and the mixer, and = kRows rows of 3 L samples for the
 // FIR: lane l then owns the three outputs whose newest-but-one sample lies in row l.
+#ifndef SDRX_LATE5_STRIDE
+#define SDRX_LATE5_STRIDE 18 // (experiment: 17 -> 9.3 KB of LDS per wave = 17 instead of 16 waves per CU, single b64 window reads; profiles/README.md round 6)
+#endif
 template <int L>
 struct LateGeom;
 template <>
 struct LateGeom<5> {
     static constexpr int kTaps = 49, kRow = 15, kRows = 64, kChunkLen = 960, kMixLanes = 60;
-    static constexpr int kStride = 18;    // LDS row stride in samples: 9 slots of 16 bytes -> the 16 lanes of a ds_read_b128 group hit 16 distinct slots,
+    static constexpr int kStride = SDRX_LATE5_STRIDE; // LDS row stride in samples (18): 9 slots of 16 bytes -> the 16 lanes of a ds_read_b128 group hit 16 distinct slots,
                                           //   and the 16 lanes of a ds_write_b64 group (pad 3: 6 dwords per row crossed) 16 distinct bank pairs
     static constexpr int kCarryRows = 4;  // rows of the previous chunk a window reaches back into: 4 x 15 >= 49
     static constexpr int kWarm = 80;      // a segment that starts inside the frame walks this many samples first: >= kTaps, a multiple of 16 L
