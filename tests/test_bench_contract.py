@@ -30,22 +30,27 @@ def _fracs(o, path=""):
             yield from _fracs(v, f"{path}[{i}]")
 
 
-@pytest.mark.parametrize("name,dom,ms,alg,workload", [("current_pmc.json", "k_mix_levels", 0.0766, 597120000, "config3"),
-                                                      ("pmc_10k.json", "k_mix_levels", 0.70, 5905536000, "10k"),
-                                                      ("pmc_flat.json", "k_mix_decimate(level0)", 0.36, 3145728000, "flat"),
-                                                      ("pmc_config4.json", "k_mix_levels", 0.032, 135840000, "config4")])
-def test_roofline_object_keeps_the_contract_keys(name, dom, ms, alg, workload):
+@pytest.mark.parametrize("name,dom,ms,alg,workload,arith", [("current_pmc.json", "k_mix_levels", 0.0766, 597120000, "config3", 1),
+                                                            ("pmc_10k.json", "k_mix_levels", 0.70, 5905536000, "10k", 1),
+                                                            ("pmc_flat.json", "k_mix_decimate(level0)", 0.36, 3145728000, "flat", 1),
+                                                            ("pmc_config4.json", "k_mix_levels", 0.032, 135840000, "config4", 1),
+                                                            ("pmc_config3_tolerance.json", "k_mix_levels", 0.060, 597120000, "config3", 0),
+                                                            ("pmc_config3_robust.json", "k_mix_levels", 0.065, 597120000, "config3", 2),
+                                                            ("pmc_10k_robust.json", "k_mix_levels", 0.59, 5905536000, "10k", 2),
+                                                            ("pmc_config4_robust.json", "k_mix_levels", 0.027, 135840000, "config4", 2)])
+def test_roofline_object_keeps_the_contract_keys(name, dom, ms, alg, workload, arith):
     """`frac` is the fraction of the bound that binds (<= 1 by construction), `bound` is that limiter -- never a label that
     disagrees with the counters -- and SURVEY 8d's algorithmic figure, which may exceed the peak, is not called a fraction."""
     b = _bench()
     pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+    assert int(pm["exact"]) == arith and pm["workload"] == workload and pm is not None and b.pmc_for(workload, arith)["source"] == pm["source"]
     if dom not in pm["kernels"]:
         dom = next(k for k in pm["kernels"] if k.startswith("k_mix"))
     from sdrreceiver_amd import topology as tp
     topo = {"config3": lambda: tp.config3(1024), "10k": lambda: tp.config3(10240), "flat": lambda: tp.config3_flat(1024),
             "config4": lambda: tp.config4(256)}[workload]()
     r = b.roofline_object(dom, {"alg_bytes": alg * 20, "launches": 20, "ms": ms * 20}, 20, 2 * ms, alg, 1, pm, 70000,
-                          b.demanded_valu_per_launch(topo))
+                          b.demanded_valu_per_launch(topo, arith))
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_GBps", "frac_hbm_unique"):
         assert k in r, k
     assert r["bound"] in ("hbm", "valu") and r["bound"] == r["limiter"]
@@ -82,7 +87,7 @@ def test_no_committed_kernel_reads_more_than_fully_busy():
     assert len(cal) == 13
     for name, p in cal.items():
         assert 0.93 <= p["valu_busy_raw"] <= 0.99, (name, p)
-    for f in ("current_pmc.json", "pmc_10k.json", "pmc_flat.json", "pmc_config4.json"):
+    for f in sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc.json") or n.startswith("pmc_")):
         pm = json.load(open(os.path.join(ROOT, "profiles", f)))
         for k, e in pm["kernels"].items():
             if "valu" in e:

@@ -31,9 +31,9 @@ import sys
 N_SIMD = 1024  # 256 CUs x 4
 N_SE = 32      # 8 XCDs x 4 shader engines: SQ_BUSY_CYCLES is summed over them
 
-KERNEL_KEYS = {
-    "k_mix_decimate<true, 1>": "k_mix_decimate(sub)", "k_mix_decimate<false, 1>": "k_mix_decimate(sub)",
-    "k_mix_decimate<true, 0>": "k_mix_decimate(level0)", "k_mix_decimate<false, 0>": "k_mix_decimate(level0)",
+KERNEL_KEYS = {  # (substrings of the demangled names: k_mix_decimate<EXACT, LEVEL, ROT>)
+    "k_mix_decimate<true, 1": "k_mix_decimate(sub)", "k_mix_decimate<false, 1": "k_mix_decimate(sub)",
+    "k_mix_decimate<true, 0": "k_mix_decimate(level0)", "k_mix_decimate<false, 0": "k_mix_decimate(level0)",
     "k_usb_demod": "k_usb_demod", "k_late_decimate": "k_late_decimate", "k_compress": "k_compress",
     "k_ingest": "k_ingest", "k_mix_levels": "k_mix_levels",
 }
