@@ -2,7 +2,8 @@
 //
 // Compiled with -ffp-contract=off: every a*b+c below is two roundings unless fmaf() is
 // spelled out.  That is what makes the EXACT variants reproduce the reference's -O2 x86-64
-// arithmetic bit for bit; the FAST variants use explicit fmaf().
+// arithmetic bit for bit; the FAST variants use explicit fmaf() (option "exact" = 0: and the NCO table as
+// rotations of its exact checkpoints, ROT; = 2, the robust arithmetic: FMAs, but the table replayed exactly).
 //
 // Kernel map (reference function -> kernel):
 //   Oscillator::Oscillator            oscillator.cpp:4-32      -> k_nco_init
@@ -10,7 +11,7 @@
 //   HalfBandDecimator::decimate       halfbanddecimator.cpp:43-72 } k_mix_decimate
 //     FIR::...HalfBandQueue           dsp.cpp:96-173           /
 //   vfo::usb_decimdemod (FIR part)    vfo.cpp:334-387          -> k_late_decimate
-//   vfo::usb_demod / demod tail       vfo.cpp:300-332,350-364  -> k_usb_demod
+//   vfo::usb_demod / demod tail       vfo.cpp:300-332,350-364  -> k_usb_demod  (option fuse_demod: demod_chunk inside the d = 2 leaf's mix wave)
 //   vfo::compress                     vfo.cpp:389-424          -> k_compress
 //
 // Execution model: 64-wide wavefronts.  k_mix_decimate runs ONE wave per workgroup and one

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -154,6 +155,7 @@ struct sdrx_ctx {
     unsigned char *h_in[2] = {nullptr, nullptr}; // pinned staging of host-fed frames, per frame parity
     size_t h_in_bytes = 0;
     int in_flight = 0;               // frames submitted (sdrx_submit*) and not yet delivered (sdrx_wait)
+    bool broken = false;             // fault injection (SDRX_FAULT_WAIT): every frame call fails from here on, like after a HIP error
     int host_slot = -1;              // which h_pay holds the payloads sdrx_get_output serves
     float2 *d_raw[2] = {nullptr, nullptr}; // host-fed frames on the device (natural order), per frame parity: frame f's
                                            //   buffer stays untouched until f+2 is staged (another context on this device may
@@ -1638,6 +1640,8 @@ namespace {
 
 int check_frame_call(sdrx_ctx *c, const char *what, const void *ptr, int n_complex, bool sync_call)
 {
+    if (c && c->broken)
+        return fail(c, SDRX_EHIP, "%s: injected fault (SDRX_FAULT_WAIT): the context is unusable", what);
     if (!c)
         return SDRX_EINVAL;
     if (!ptr)
@@ -1926,10 +1930,25 @@ int start_owed_copy(sdrx_ctx *c)
     return SDRX_OK;
 }
 // the oldest undelivered frame's payloads are in host memory afterwards (slot returned); no callbacks
+// Fault injection for the hosts' error paths (tests/test_dropin_qt.py): SDRX_FAULT_WAIT=k makes the k-th sdrx_wait of the PROCESS
+// fail like a HIP error does -- before the frame leaves the queue, and for good: every later frame call of that context fails
+// too (HIP errors are sticky).  One shot per process, so that a host which recovers by building a new context gets a sound one.
+bool injected_fault(sdrx_ctx *c, bool at_wait)
+{
+    static std::atomic<long> countdown{getenv("SDRX_FAULT_WAIT") ? atol(getenv("SDRX_FAULT_WAIT")) : 0};
+    if (c->broken)
+        return true;
+    if (at_wait && countdown.load() > 0 && countdown.fetch_sub(1) == 1)
+        c->broken = true;
+    return c->broken;
+}
+
 int wait_frame(sdrx_ctx *c, int *slot)
 {
     if (c->in_flight <= 0)
         return fail(c, SDRX_ESTATE, "sdrx_wait: no submitted frame is in flight");
+    if (injected_fault(c, true))
+        return fail(c, SDRX_EHIP, "sdrx_wait: injected fault (SDRX_FAULT_WAIT): the context is unusable from here on");
     int rc = start_owed_copy(c);
     if (rc)
         return rc;
