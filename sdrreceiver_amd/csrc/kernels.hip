@@ -2249,12 +2249,103 @@ __global__ __launch_bounds__(64, SDRX_LATE4_WAVES) void k_late_decimate4(const K
 constexpr int kDemodTile = 1024;
 constexpr int kPlaneLen = (kDemodTile + kMaxFir + kHilbert + 1) / 2 + 8;
 
+// ---- the non-exact arithmetics' MACs, two outputs per instruction ----------------------------------------------------------
+// Four outputs r = 0..3 of a thread share a window: at window entry k output r takes tap h[k - r] (the Hilbert sum: outputs
+// t0 + 2 r on one parity plane; the audio low-pass: four consecutive outputs).  As scalar FMAs that is four instructions per
+// entry, and a v_fma_f32 pairs with another wave's instruction far less often than a two-operand v_mul / v_add does (37 % of
+// k_usb_demod's instructions in the tolerance arithmetic against 80 % in the exact one: profiles/pmc_config3_tolerance.json).  As
+// PACKED FMAs it is two: A = (out0, out1) += (h[k], h[k-1]) * v[k], B = (out2, out3) += (h[k-2], h[k-3]) * v[k].  The pair
+// (h[k-1], h[k]) is an aligned register pair of one of two copies of the taps -- E: pairs (h[2j-1], h[2j]), O: pairs
+// (h[2j], h[2j+1]) -- taken SWAPPED (op_sel / op_sel_hi on the tap operand), v[k] either half of an aligned pair for both
+// lanes.  Every lane of every instruction is the same fma(h, v, acc) in the same order as the scalar form: bit-identical.
+template <int H>
+__device__ __forceinline__ void pk_fma2_s(v2f &A, v2f &B, v2f pa, v2f pb, v2f vv) // taps: scalar register pairs
+{
+    asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel:[1,%5,0] op_sel_hi:[0,%5,1]\n\t"
+        "v_pk_fma_f32 %1, %3, %4, %1 op_sel:[1,%5,0] op_sel_hi:[0,%5,1]"
+        : "+v"(A), "+v"(B)
+        : "s"(pa), "s"(pb), "v"(vv), "n"(H));
+}
+// the same in the exact arithmetic: product and sum rounded separately (v_pk_mul_f32, v_pk_add_f32), the two products first
+template <int H>
+__device__ __forceinline__ void pk_mac2_s(v2f &A, v2f &B, v2f pa, v2f pb, v2f vv)
+{
+    v2f ta, tb;
+    asm("v_pk_mul_f32 %2, %4, %6 op_sel:[1,%7] op_sel_hi:[0,%7]\n\t"
+        "v_pk_mul_f32 %3, %5, %6 op_sel:[1,%7] op_sel_hi:[0,%7]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\t"
+        "v_pk_add_f32 %1, %1, %3"
+        : "+v"(A), "+v"(B), "=&v"(ta), "=&v"(tb)
+        : "s"(pa), "s"(pb), "v"(vv), "n"(H));
+}
+template <int H>
+__device__ __forceinline__ void pk_fma2_v(v2f &A, v2f &B, v2f pa, v2f pb, v2f vv) // taps: vector register pairs
+{
+    asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel:[1,%5,0] op_sel_hi:[0,%5,1]\n\t"
+        "v_pk_fma_f32 %1, %3, %4, %1 op_sel:[1,%5,0] op_sel_hi:[0,%5,1]"
+        : "+v"(A), "+v"(B)
+        : "v"(pa), "v"(pb), "v"(vv), "n"(H));
+}
+// pair i (0..8) of the 18 floats (x16, x2) a pass has loaded
+template <int I>
+__device__ __forceinline__ v2f pair_of(v16f a, v2f b)
+{
+    if constexpr (I < 8)
+        return __builtin_shufflevector(a, a, 2 * I, 2 * I + 1);
+    else
+        return b;
+}
+// The Hilbert sum of four same-parity outputs: plane[k], k = 0 .. 64 (17 aligned b128 reads), taps hE[m] = h[m - 3], hO[m] =
+// h[m - 2] (zeros outside 0 .. 61; K2Vfo::hnz_e / hnz_o, 96 floats each): pair j' of hE = (h[2j'-3], h[2j'-2]), of hO =
+// (h[2j'-2], h[2j'-1]).  Entry k takes P(k) = (h[k-1], h[k]) for A and P(k-2) for B: P(k) = pair k/2 + 1 of hE (k even) or
+// of hO (k odd).  Sixteen entries per pass, the 2 x 18 floats of taps a pass needs requested in front of it.
+template <bool EXACT>
+__device__ __forceinline__ void hilbert4_packed(const float *plane, const float *hE, const float *hO, float (&acc)[4])
+{
+    v2f A = {0.f, 0.f}, B = {0.f, 0.f};
+    static_for<5>([&](auto pass_ic) {
+        constexpr int pass = decltype(pass_ic)::value, nk = pass < 4 ? 16 : 1; // (entry 64 feeds out3 alone: h[61])
+        const float *pe = hE + 16 * pass, *po = hO + 16 * pass;
+        asm volatile("" : "+s"(pe), "+s"(po)); // (a pass's taps are requested here, not five passes' worth up front)
+        const v16f e16 = *(const SDRX_AS4 v16f *)pe, o16 = *(const SDRX_AS4 v16f *)po;
+        const v2f e2 = *(const SDRX_AS4 v2f *)(pe + 16), o2 = *(const SDRX_AS4 v2f *)(po + 16);
+        static_for<(nk + 3) / 4>([&](auto g_ic) {
+            constexpr int g = decltype(g_ic)::value;
+            const v4f v4 = *reinterpret_cast<const v4f *>(plane + 16 * pass + 4 * g);
+            static_for<(nk < 4 ? nk : 4)>([&](auto e_ic) {
+                constexpr int e = decltype(e_ic)::value, kk = 4 * g + e, iA = kk / 2 + 1, iB = iA - 1;
+                const v2f vv = e < 2 ? lo2(v4) : hi2(v4);
+                if constexpr (EXACT) {
+                    if constexpr (kk % 2 == 0)
+                        pk_mac2_s<0>(A, B, pair_of<iA>(e16, e2), pair_of<iB>(e16, e2), vv);
+                    else
+                        pk_mac2_s<1>(A, B, pair_of<iA>(o16, o2), pair_of<iB>(o16, o2), vv);
+                } else {
+                    if constexpr (kk % 2 == 0)
+                        pk_fma2_s<0>(A, B, pair_of<iA>(e16, e2), pair_of<iB>(e16, e2), vv);
+                    else
+                        pk_fma2_s<1>(A, B, pair_of<iA>(o16, o2), pair_of<iB>(o16, o2), vv);
+                }
+            });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    acc[0] = A.x, acc[1] = A.y, acc[2] = B.x, acc[3] = B.y;
+}
+
+#ifndef SDRX_PACKED_EXACT_HILBERT
+#define SDRX_PACKED_EXACT_HILBERT 0 // (A/B: 1 = the exact arithmetic's Hilbert sum as packed v_pk_mul / v_pk_add on output pairs as well)
+#endif
+#ifndef SDRX_PACKED_LPF
+#define SDRX_PACKED_LPF 0 // (A/B: 1 = the audio low-pass of the non-exact arithmetics as packed FMAs too -- measured slower on config 4, profiles/README.md round 6)
+#endif
 struct DemodLds { // LDS of one 256-thread demodulation block
     alignas(16) float sP0[kPlaneLen + 4]; // even offsets from `lo`, stored shifted by +3
     alignas(16) float sP1[kPlaneLen + 4]; // odd offsets
     alignas(16) float sI[kDemodTile + kMaxFir + 8];
     alignas(16) float sU[kDemodTile + kMaxFir + 16];
-    alignas(16) float sH[kMaxFir + 16];
+    alignas(16) float sH[kMaxFir + 16];  // sH[m] = hu[m - 3]: the E pairs of the packed form, (hu[2j'-3], hu[2j'-2])
+    alignas(16) float sH1[kMaxFir + 16]; // sH1[m] = sH[m + 1] = hu[m - 2]: the O pairs (non-exact arithmetics only)
 };
 static_assert(sizeof(DemodLds) % 16 == 0, "DemodLds is a whole number of 16-byte units");
 
@@ -2262,7 +2353,7 @@ template <bool EXACT>
 __device__ __forceinline__ void demod_block(const K2Vfo *__restrict__ vfos, const BlockWork bw, unsigned long long frame_no, DemodLds &S,
                                             int tid)
 {
-    float *sP0 = S.sP0, *sP1 = S.sP1, *sI = S.sI, *sU = S.sU, *sH = S.sH;
+    float *sP0 = S.sP0, *sP1 = S.sP1, *sI = S.sI, *sU = S.sU, *sH = S.sH, *sH1 = S.sH1;
     const K2Vfo *Dp = vfos + bw.vfo;
     const int blk = bw.blk;
     const int par = (int)(frame_no & 1ull);
@@ -2281,14 +2372,21 @@ __device__ __forceinline__ void demod_block(const K2Vfo *__restrict__ vfos, cons
     if (m0 >= D.n && blk != 0)
         return;
     // The 62 Hilbert taps, read before this kernel has stored anything so the compiler can use
-    // wave-uniform scalar loads and keep them in SGPRs for the whole block.
+    // wave-uniform scalar loads and keep them in SGPRs for the whole block.  (The non-exact arithmetics take them pass by
+    // pass as register PAIRS instead: hilbert4_packed.)
+    constexpr bool kPackedHilbert = !EXACT || SDRX_PACKED_EXACT_HILBERT;
     float hnz[kHilbertNz];
+    if constexpr (!kPackedHilbert) {
 #pragma unroll
-    for (int s = 0; s < kHilbertNz; ++s)
-        hnz[s] = ldc(D.hnz + s);
+        for (int s = 0; s < kHilbertNz; ++s)
+            hnz[s] = ldc(D.hnz + s);
+    }
     if (D.nlpf > 0)
-        for (int j = tid; j < D.nlpf + 15; j += 256)
+        for (int j = tid; j < D.nlpf + 15; j += 256) {
             sH[j] = gld(D.lpf + j);
+            if constexpr (!EXACT)
+                sH1[j] = j + 1 < D.nlpf + 15 ? gld(D.lpf + j + 1) : 0.f;
+        }
     if (blk == 0) // history for the next frame: the last H entries of [hist | data]
         for (int j = tid; j < D.H; j += 256)
             gst2(snext + j, gld2(sbase + D.n + j));
@@ -2331,22 +2429,22 @@ __device__ __forceinline__ void demod_block(const K2Vfo *__restrict__ vfos, cons
             continue;
         const float *plane = p == 0 ? sP1 + (t0 >> 1) : sP0 + 3 + ((t0 + 1) >> 1);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!kPackedHilbert) {
 #pragma unroll
-        for (int g = 0; g < 17; ++g) {
-            const float4 v4 = *reinterpret_cast<const float4 *>(plane + 4 * g);
-            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            for (int g = 0; g < 17; ++g) {
+                const float4 v4 = *reinterpret_cast<const float4 *>(plane + 4 * g);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int s = 4 * g + e - rr;
-                    if (s >= 0 && s < kHilbertNz) {
-                        if (EXACT)
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int s = 4 * g + e - rr;
+                        if (s >= 0 && s < kHilbertNz)
                             acc[rr] = acc[rr] + hnz[s] * v[e];
-                        else
-                            acc[rr] = fmaf(hnz[s], v[e], acc[rr]);
                     }
-                }
+            }
+        } else {
+            hilbert4_packed<EXACT>(plane, ldc(&Dp->hnz_e), ldc(&Dp->hnz_o), acc);
         }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
@@ -2370,20 +2468,38 @@ __device__ __forceinline__ void demod_block(const K2Vfo *__restrict__ vfos, cons
         const float *w = sU + soff + (E - N) + j0; // 16-byte aligned by the choice of soff
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         const int groups = (N + 6) / 4;
-        for (int g = 0; g < groups; ++g) {
-            const float4 v4 = *reinterpret_cast<const float4 *>(w + 4 * g);
-            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-            const float4 ha = *reinterpret_cast<const float4 *>(sH + 4 * g), hb4 = *reinterpret_cast<const float4 *>(sH + 4 * g + 4);
-            const float h[8] = {ha.x, ha.y, ha.z, ha.w, hb4.x, hb4.y, hb4.z, hb4.w}; // h[k] = hu[4g + k - 3]
+        if constexpr (EXACT || !SDRX_PACKED_LPF) {
+            for (int g = 0; g < groups; ++g) {
+                const float4 v4 = *reinterpret_cast<const float4 *>(w + 4 * g);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                const float4 ha = *reinterpret_cast<const float4 *>(sH + 4 * g), hb4 = *reinterpret_cast<const float4 *>(sH + 4 * g + 4);
+                const float h[8] = {ha.x, ha.y, ha.z, ha.w, hb4.x, hb4.y, hb4.z, hb4.w}; // h[k] = hu[4g + k - 3]
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    if (EXACT)
-                        acc[rr] = acc[rr] + h[e - rr + 3] * v[e];
-                    else
-                        acc[rr] = fmaf(h[e - rr + 3], v[e], acc[rr]);
-                }
+                    for (int rr = 0; rr < 4; ++rr) {
+                        if (EXACT)
+                            acc[rr] = acc[rr] + h[e - rr + 3] * v[e];
+                        else
+                            acc[rr] = fmaf(h[e - rr + 3], v[e], acc[rr]);
+                    }
+            }
+        } else {
+            // the packed form (see hilbert4_packed): window entry q = 4 g + e gives out_r the tap hu[q - r]; quad t of sH holds
+            // the E pairs 2 t, 2 t + 1 -- (hu[4t-3], hu[4t-2]), (hu[4t-1], hu[4t]) --, of sH1 the O pairs (hu[4t-2], hu[4t-1]),
+            // (hu[4t], hu[4t+1]); a group needs the pairs 2 g, 2 g + 1 (the quad before) and 2 g + 2 (this one's low half)
+            v2f A = {0.f, 0.f}, B = {0.f, 0.f};
+            v4f ep = *reinterpret_cast<const v4f *>(sH), op = *reinterpret_cast<const v4f *>(sH1);
+            for (int g = 0; g < groups; ++g) {
+                const v4f w4 = *reinterpret_cast<const v4f *>(w + 4 * g);
+                const v4f ec = *reinterpret_cast<const v4f *>(sH + 4 * g + 4), oc = *reinterpret_cast<const v4f *>(sH1 + 4 * g + 4);
+                pk_fma2_v<0>(A, B, hi2(ep), lo2(ep), lo2(w4)); // q = 4g:     (hu[4g-1], hu[4g])   | (hu[4g-3], hu[4g-2])
+                pk_fma2_v<1>(A, B, hi2(op), lo2(op), lo2(w4)); // q = 4g + 1: (hu[4g],   hu[4g+1]) | (hu[4g-2], hu[4g-1])
+                pk_fma2_v<0>(A, B, lo2(ec), hi2(ep), hi2(w4)); // q = 4g + 2: (hu[4g+1], hu[4g+2]) | (hu[4g-1], hu[4g])
+                pk_fma2_v<1>(A, B, lo2(oc), hi2(op), hi2(w4)); // q = 4g + 3: (hu[4g+2], hu[4g+3]) | (hu[4g],   hu[4g+1])
+                ep = ec, op = oc;
+            }
+            acc[0] = A.x, acc[1] = A.y, acc[2] = B.x, acc[3] = B.y;
         }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)

@@ -53,6 +53,8 @@ struct Node {
     // designed taps (host copies for sdrx_get_taps)
     std::vector<float> lpf, dec, hilbert;
     std::vector<float> lpf_pad, hnz; // device forms: zero-padded low-pass, compacted Hilbert
+    std::vector<float> hnz_e, hnz_o; //   ... and the compacted Hilbert taps shifted by 3 / 2 in 96 zero-padded floats (hilbert4_packed)
+    size_t off_hnz_e = 0, off_hnz_o = 0;
     int demod_tile = 1024;           // outputs per k_usb_demod block
     bool long_lpf = false;           // audio low-pass of more than kMaxFir taps: applied by k_lpf_long
     int Hu = 0;                      // its history length (usb floats of the previous frame)
@@ -963,6 +965,10 @@ int derive_nodes(sdrx_ctx *c)
                 else if (n.hilbert[(size_t)t] != 0.0f)
                     return fail(c, SDRX_EUNSUPPORTED, "vfo %d: even Hilbert tap %d is not zero", i, t);
             }
+            n.hnz_e.assign(96, 0.0f);
+            n.hnz_o.assign(96, 0.0f);
+            std::copy(n.hnz.begin(), n.hnz.end(), n.hnz_e.begin() + 3);
+            std::copy(n.hnz.begin(), n.hnz.end(), n.hnz_o.begin() + 2);
             if (!n.lpf.empty() && !n.long_lpf) {
                 n.lpf_pad.assign(n.lpf.size() + 3 + 12, 0.0f);
                 std::copy(n.lpf.begin(), n.lpf.end(), n.lpf_pad.begin() + 3);
@@ -1042,8 +1048,11 @@ void plan_buffers(sdrx_ctx *c, Built &B)
             for (int p = 0; p < 2; ++p)
                 n.off_u[p] = plan.take(sizeof(float) * (size_t)(n.Hu + n.n_out));
         }
-        if (!n.hnz.empty())
+        if (!n.hnz.empty()) {
             n.off_hnz = B.place_taps(n.hnz);
+            n.off_hnz_e = B.place_taps(n.hnz_e);
+            n.off_hnz_o = B.place_taps(n.hnz_o);
+        }
         if (!n.dec.empty())
             n.off_dec = B.place_taps(n.dec);
         if (!n.hilbert.empty())
@@ -1427,6 +1436,8 @@ int allocate_and_upload(sdrx_ctx *c, Built &B)
             k.s_next[p] = n.fused_demod ? nullptr : reinterpret_cast<float2 *>(P(late ? n.off_z[p ^ 1] : n.off_stream[p ^ 1]));
         }
         k.hnz = reinterpret_cast<const float *>(P(n.off_hnz));
+        k.hnz_e = reinterpret_cast<const float *>(P(n.off_hnz_e));
+        k.hnz_o = reinterpret_cast<const float *>(P(n.off_hnz_o));
         k.lpf_pad = (n.lpf.empty() || n.long_lpf) ? nullptr : reinterpret_cast<const float *>(P(n.off_lpf));
         for (int p = 0; p < 2; ++p) {
             k.usb_out[p] = n.long_lpf ? reinterpret_cast<float *>(P(n.off_u[p])) + n.Hu : nullptr;

@@ -128,6 +128,8 @@ struct K2Vfo {
     int pad_;
     float *usb_out[2];      // a low-pass longer than kMaxFir: the unfiltered usb floats go here per frame parity
                             //   (behind that stream's history) and k_lpf_long does the rest; else null
+    const float *hnz_e, *hnz_o; // the same taps for the packed MACs of the non-exact arithmetics (hilbert4_packed): hnz_e[m] = h[m-3],
+                            //   hnz_o[m] = h[m-2] with h[s] = hnz[s], zeros outside 0 .. 61; 96 floats each
     float *state[2];        // a leaf that demodulates in its mix wave: its demodulation history per frame parity (256 floats:
                             //   the last 62 odd / 62 even Q, 62 I and Nh usb values at 64-float strides); else null
 };
