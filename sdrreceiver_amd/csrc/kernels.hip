@@ -2345,7 +2345,7 @@ struct DemodLds { // LDS of one 256-thread demodulation block
     alignas(16) float sI[kDemodTile + kMaxFir + 8];
     alignas(16) float sU[kDemodTile + kMaxFir + 16];
     alignas(16) float sH[kMaxFir + 16];  // sH[m] = hu[m - 3]: the E pairs of the packed form, (hu[2j'-3], hu[2j'-2])
-    alignas(16) float sH1[kMaxFir + 16]; // sH1[m] = sH[m + 1] = hu[m - 2]: the O pairs (non-exact arithmetics only)
+    alignas(16) float sH1[SDRX_PACKED_LPF ? kMaxFir + 16 : 4]; // sH1[m] = sH[m + 1] = hu[m - 2]: the O pairs (the packed low-pass only)
 };
 static_assert(sizeof(DemodLds) % 16 == 0, "DemodLds is a whole number of 16-byte units");
 
@@ -2384,7 +2384,7 @@ __device__ __forceinline__ void demod_block(const K2Vfo *__restrict__ vfos, cons
     if (D.nlpf > 0)
         for (int j = tid; j < D.nlpf + 15; j += 256) {
             sH[j] = gld(D.lpf + j);
-            if constexpr (!EXACT)
+            if constexpr (!EXACT && SDRX_PACKED_LPF)
                 sH1[j] = j + 1 < D.nlpf + 15 ? gld(D.lpf + j + 1) : 0.f;
         }
     if (blk == 0) // history for the next frame: the last H entries of [hist | data]
@@ -2534,8 +2534,11 @@ __device__ __forceinline__ void demod_block(const K2Vfo *__restrict__ vfos, cons
     }
 }
 
+#ifndef SDRX_DEMOD_MIN_WAVES
+#define SDRX_DEMOD_MIN_WAVES 1 // (A/B: 8 = at most 64 VGPRs, eight 256-thread blocks per CU)
+#endif
 template <bool EXACT>
-__global__ __launch_bounds__(256) void k_usb_demod(const K2Vfo *__restrict__ vfos, const BlockWork *__restrict__ work,
+__global__ __launch_bounds__(256, SDRX_DEMOD_MIN_WAVES) void k_usb_demod(const K2Vfo *__restrict__ vfos, const BlockWork *__restrict__ work,
                                                    unsigned long long frame_no)
 {
     __shared__ __attribute__((aligned(16))) DemodLds S;
