@@ -506,6 +506,11 @@ def main():
     share = os.environ.get("SDRX_BENCH_SHARE_GPU") == "1"
     if share:
         local = 0
+    # a launcher that gives every rank ONE visible device (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = its own GPU): that device is
+    # ordinal 0 in this process, whatever LOCAL_RANK says -- and rank 0's device is not visible, so peer access cannot be asked here
+    one_visible = (not share) and world > 1 and torch.cuda.device_count() == 1
+    if one_visible:
+        local = 0
     torch.cuda.set_device(local)
     from sdrreceiver_amd import distributed as D, synth, topology as tp
     from sdrreceiver_amd.receiver import Receiver
@@ -545,7 +550,7 @@ def main():
         # so that the first run on several devices diagnoses itself: what the process group says, who reaches whom
         diag_world = dist.get_world_size()
         try:
-            ok = 1 if (local == 0 or share) else int(torch.cuda.can_device_access_peer(local, 0))
+            ok = 1 if (rank == 0 or share) else -1 if one_visible else int(torch.cuda.can_device_access_peer(local, 0))
         except Exception:
             ok = -1
         if os.environ.get("SDRX_BENCH_FAKE_NO_PEER") == "1" and rank == world - 1:
