@@ -94,6 +94,28 @@ def test_no_committed_kernel_reads_more_than_fully_busy():
                 assert 0.0 <= e["valu"].get("valu_busy", e["valu"]["valu_busy_raw"]) <= 1.0, (f, k)
 
 
+def test_counter_summaries_know_every_kernel_of_the_committed_traces():
+    """tools/pmc_summary.py maps demangled kernel names to the keys bench.py looks up; round 6 added a template parameter to
+    k_mix_decimate and the flat workload's dominant kernel silently fell out of its summary.  Every kernel of the product in the
+    committed round-6 traces must map, and every summary must hold the dominant kernel of its workload."""
+    import csv
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+    ps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ps)
+    seen = set()
+    for d in sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.startswith("r06") and os.path.exists(os.path.join(ROOT, "profiles", n, "kernel_stats.csv"))):
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", d, "kernel_stats.csv"))):
+            if "sdrx::k_" in r["Name"] and "k_nco_init" not in r["Name"]:
+                assert ps.key_of(r["Name"]) is not None, (d, r["Name"])
+                seen.add(ps.key_of(r["Name"]))
+    assert {"k_mix_levels", "k_usb_demod", "k_mix_decimate(level0)", "k_ingest"} <= seen, seen
+    for f, dom in (("current_pmc.json", "k_mix_levels"), ("pmc_flat.json", "k_mix_decimate(level0)"), ("pmc_10k.json", "k_mix_levels"),
+                   ("pmc_config4.json", "k_mix_levels"), ("pmc_config3_robust.json", "k_mix_levels"), ("pmc_config3_tolerance.json", "k_mix_levels")):
+        pm = json.load(open(os.path.join(ROOT, "profiles", f)))
+        assert dom in pm["kernels"] and "valu" in pm["kernels"][dom] and "hbm_bytes_per_launch" in pm["kernels"][dom], (f, list(pm["kernels"]))
+        assert len({json.load(open(os.path.join(ROOT, "profiles", g)))["build_id"] for g in ("current_pmc.json", f)}) == 1  # one build
+
+
 def test_printed_line_stays_under_8_kb():
     """the driver could not parse the 22.7 KB line of round 5.  `compact_line` turns everything a run
     measures (here: that very line, committed as profiles/r05/bench_default_with_cpu_baseline.json) into the printed line:
