@@ -170,7 +170,9 @@ class Verifier:
         j = self.job
         t0 = time.perf_counter()
         threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        threads = max(1, min(threads, 32))  # (two short parallel regions per frame: 256 threads on the 2 x 64-core host took 30x as long as 32)
+        # (two short parallel regions per frame: 256 threads on the 2 x 64-core host took 30x as long as 32; at N > 1 every rank runs
+        # its own oracle at the same time: the ranks share the host's cores)
+        threads = max(1, min(threads // max(1, int(os.environ.get("WORLD_SIZE", "1"))), 32))
         nodes, roots = ob.build_tree("port", self.sub)
         done, bad, worst, checked = 0, [], 0.0, 0
         try:
