@@ -1099,8 +1099,12 @@ int build_mix_work(sdrx_ctx *c, Built &B)
             ncu = prop.multiProcessorCount;
     }
     std::vector<int> level_nseg((size_t)c->n_levels, 1);
+    // (experiment switches, read here: SDRX_ITEMS_PER_CU = work items per CU a level is cut into, default 32; SDRX_MIN_SEG = the
+    // fewest chunks of useful work a segment of a many-VFO level may have, default 4)
+    const int items_per_cu = getenv("SDRX_ITEMS_PER_CU") ? std::max(1, atoi(getenv("SDRX_ITEMS_PER_CU"))) : 32;
+    const int min_seg_chunks = getenv("SDRX_MIN_SEG") ? std::max(1, atoi(getenv("SDRX_MIN_SEG"))) : 4;
     for (int lv = 0; lv < c->n_levels; ++lv) // 32 work items per CU (= the hardware's wave slots per CU)
-        level_nseg[(size_t)lv] = std::max(1, (ncu * 32 + B.level_count[(size_t)lv] - 1) / B.level_count[(size_t)lv]);
+        level_nseg[(size_t)lv] = std::max(1, (ncu * items_per_cu + B.level_count[(size_t)lv] - 1) / B.level_count[(size_t)lv]);
     c->mix_chunks = 0;
     for (int i = 0; i < N; ++i) {
         const Node &n = c->nodes[(size_t)i];
@@ -1121,7 +1125,7 @@ int build_mix_work(sdrx_ctx *c, Built &B)
         // (a fused late decimation: measured on config 4, interleaved: 2 / 3 / 4 / 6 / 8 chunks per segment = 0.0481 / 0.0484 /
         // 0.0471 / 0.0482 / 0.0509 ms per step; SDRX_LATE_MINSEG for A/B runs)
         const int late_min_seg = getenv("SDRX_LATE_MINSEG") ? std::max(1, atoi(getenv("SDRX_LATE_MINSEG"))) : 4;
-        const int min_seg = few ? std::max(1, wch) : n.fused_late ? late_min_seg : std::max(4, 4 * wch);
+        const int min_seg = few ? std::max(1, wch) : n.fused_late ? late_min_seg : std::max(min_seg_chunks, min_seg_chunks * wch);
         int nseg = c->opt_segments > 0 ? c->opt_segments : std::min(level_nseg[(size_t)n.level], std::max(1, nchunks / min_seg));
         nseg = std::max(1, std::min(nseg, nchunks / std::max(1, wch)));
         // Segment s > 0 starts `warm` samples before its first emitted output and ends on a chunk
