@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/r6_collect.sh -- copy what tools/r6e.sh left in gpurun_out/ into profiles/r06* and regenerate the counter summaries
 set -e
-for d in r06 r06_10k r06_flat r06_config4 r06_tolerance r06_10k_tolerance r06_config4_tolerance r06_robust r06_10k_robust r06_config4_robust r06_fuse_demod; do
+for d in r06 r06_10k r06_flat r06_config4 r06_tolerance r06_10k_tolerance r06_config4_tolerance r06_robust r06_10k_robust r06_config4_robust r06_fuse_demod r06_flat10k r06_64k; do
   [ -d gpurun_out/prof_$d ] || { echo "missing gpurun_out/prof_$d"; continue; }
   mkdir -p profiles/$d
   cp gpurun_out/prof_$d/bench.json gpurun_out/prof_$d/bench_unprofiled.json gpurun_out/prof_$d/build_sha.txt profiles/$d/
@@ -19,3 +19,5 @@ python tools/pmc_summary.py profiles/r06_robust profiles/pmc_config3_robust.json
 python tools/pmc_summary.py profiles/r06_10k_robust profiles/pmc_10k_robust.json 10k 2
 python tools/pmc_summary.py profiles/r06_config4_robust profiles/pmc_config4_robust.json config4 2
 python tools/pmc_summary.py profiles/r06_fuse_demod profiles/r06_fuse_demod/pmc_summary.json config3 1
+[ -d profiles/r06_flat10k ] && python tools/pmc_summary.py profiles/r06_flat10k profiles/pmc_flat10k.json flat10k 1
+[ -d profiles/r06_64k ] && python tools/pmc_summary.py profiles/r06_64k profiles/pmc_64k.json 64k 1

@@ -17,3 +17,7 @@ bash tools/profile.sh r06_10k_robust --workload 10k --arith 2 >> $L 2>&1
 bash tools/profile.sh r06_config4_robust --workload config4 --arith 2 >> $L 2>&1
 bash tools/profile.sh r06_fuse_demod --option fuse_demod=1 >> $L 2>&1
 tail -3 $L
+# (added later in the round: the two largest side workloads, so that their rows carry a roofline too)
+bash tools/profile.sh r06_flat10k --workload flat10k >> $L 2>&1
+bash tools/profile.sh r06_64k --workload 64k >> $L 2>&1
+tail -3 $L
